@@ -1,0 +1,151 @@
+/*
+ * adypt_hip.h — C-ABI of the MI355X-native tracer that replaces Adypt's src/Tracer (OglScene + OglPathTracer)
+ * and the three GLSL compute programs (shaders/{traversal,primaryray,pathtracer}.glsl).
+ *
+ * The reference has no FFI/plugin layer: the seam is the two C++ classes OglScene and OglPathTracer that
+ * Instance (src/Instance.cpp:33-35,44-57) and Application (src/Application.cpp:108-109,220-234,275) call.
+ * Every entry point below names the reference interface it stands in for.  Plain pointers and sizes only;
+ * the caller owns all host arrays, the callee copies them to HBM at create time (mirrors the immutable
+ * glNamedBufferStorage(..., flags = 0) uploads of src/Tracer/OglScene.cpp:125-134).
+ *
+ * Threading: one host thread drives a context; calls are synchronous unless stated; a context is bound to one
+ * HIP device and owns one HIP stream.  No exceptions cross this boundary: every call returns ADYPT_OK (0) or a
+ * negative ADYPT_E_* code and adypt_last_error() gives the text (the reference printf()s and returns bool).
+ */
+#ifndef ADYPT_HIP_H
+#define ADYPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADYPT_ABI_VERSION 1
+
+enum adypt_status {
+	ADYPT_OK = 0,
+	ADYPT_E_INVALID = -1,        /* bad argument / inconsistent array sizes */
+	ADYPT_E_NO_DEVICE = -2,      /* no HIP device (the product has no CPU fallback) */
+	ADYPT_E_HIP = -3,            /* HIP runtime error, text in adypt_last_error */
+	ADYPT_E_OOM = -4,
+	ADYPT_E_STACK_OVERFLOW = -5, /* traversal needed more than stackSize entries (reference: undefined behaviour, traversal.glsl:60) */
+	ADYPT_E_BAD_MATERIAL = -6,   /* a hit triangle has material id outside [0, n_mats) (reference: uMaterials[-1], pathtracer.glsl:77) */
+	ADYPT_E_IO = -7,
+	ADYPT_E_PARSE = -8,
+	ADYPT_E_STATE = -9           /* call order violated (e.g. trace before set_camera) */
+};
+
+typedef struct adypt_ctx adypt_ctx;
+
+/* One decoded texture: RGB8, rows top to bottom exactly as stbi_load(..., 3) returns them
+ * (src/Tracer/OglScene.cpp:26-34); sampled GL_LINEAR / GL_REPEAT / single level (:33-38). */
+typedef struct adypt_texture {
+	int32_t width, height;
+	const uint8_t *rgb;
+} adypt_texture;
+
+/* Inputs of OglScene::Initialize(const Scene&, const WideBVH&) (src/Tracer/OglScene.hpp:43) + the image size
+ * OglPathTracer::Initialize receives (src/Tracer/OglPathTracer.cpp:11-16), as flat arrays. */
+typedef struct adypt_scene_desc {
+	const void *nodes;           /* WideBVH::GetNodes(): 80-byte WideBVHNode (src/BVH/WideBVH.hpp:13-26)          SSBO 0 */
+	int64_t n_nodes;
+	const int32_t *tri_indices;  /* WideBVH::GetTriIndices(): reference -> scene triangle                          SSBO 1 */
+	int64_t n_refs;
+	const float *woop;           /* 12 floats per reference in tri_indices order, or NULL: computed on the host
+	                                exactly as OglScene::init_triangles does (src/Tracer/OglScene.cpp:93-116)     SSBO 2 */
+	const void *triangles;       /* Scene::GetTriangles(): 100-byte Triangle (src/Util/Shape.hpp:70-74)            SSBO 3 */
+	int64_t n_tris;
+	const void *materials;       /* 64-byte GPUMaterial (src/Tracer/OglScene.hpp:19-28)                            SSBO 4 */
+	int64_t n_mats;
+	const adypt_texture *textures; /* bindless sampler table (OglScene.cpp:84-90)                                   UBO 3 */
+	int32_t n_textures;
+	int32_t width, height;       /* IMG_SIZE */
+	int32_t device;              /* HIP device ordinal */
+	int32_t tile_rank;           /* pixel-tile shard: this context renders the 32x32 blocks whose owner is tile_rank */
+	int32_t tile_nranks;         /* 1 = whole image */
+} adypt_scene_desc;
+
+/* InstanceConfig::PT (src/InstanceConfig.hpp:21-27) as consumed by update_config_args (OglPathTracer.cpp:214-225),
+ * plus the explicit seed that replaces std::random_device in create_buffers (OglPathTracer.cpp:156-162). */
+typedef struct adypt_pt_params {
+	int32_t stack_size, max_bounce, subpixel, tmp_lifetime;
+	float ray_tmin, clamp, sun[3];
+	uint32_t shift_seed;
+} adypt_pt_params;
+
+/* One closest-hit record (outputs of BVHIntersection, traversal.glsl:14,253-254, + instrumentation). */
+typedef struct adypt_hit {
+	int32_t ref_idx;   /* index into tri_indices / woop (pre-remap), -1 = miss */
+	int32_t tri_id;    /* uTriIndices[ref_idx], -1 = miss */
+	float u, v, t;
+	uint32_t nodes, tris, hash, max_depth; /* filled only by the instrumented kernel variant (with_stats) */
+} adypt_hit;
+
+typedef struct adypt_stats {
+	uint64_t rays;            /* BVHIntersection invocations (cached primaries are not rays) */
+	uint64_t nodes_visited;   /* instrumented runs only */
+	uint64_t tris_tested;     /* instrumented runs only */
+	uint64_t hits;            /* instrumented runs only */
+	uint64_t shaded;          /* FetchInfo executions */
+	uint64_t stack_overflows;
+	uint64_t bad_materials;
+	uint32_t max_stack;       /* instrumented runs only */
+	uint32_t trace_launches;
+	double trace_ms;          /* sum of HIP-event durations of the traversal kernel launches (timing enabled) */
+	double shade_ms;          /* same for gen/shade kernels */
+} adypt_stats;
+
+int adypt_abi_version(void);
+
+/* OglScene::Initialize + OglPathTracer::Initialize (create_buffers / bind_buffers).  Fails with ADYPT_E_NO_DEVICE
+ * when no GPU is present. */
+int adypt_create(adypt_ctx **out, const adypt_scene_desc *desc);
+void adypt_destroy(adypt_ctx *ctx);
+const char *adypt_last_error(const adypt_ctx *ctx); /* ctx may be NULL: error of the last failed adypt_create */
+
+/* OglPathTracer::update_config_args (OglPathTracer.cpp:214-225); also (re)generates the per-pixel Sobol shift
+ * image from shift_seed.  Like the reference, new values take effect for path tracing at the next adypt_reset(). */
+int adypt_set_params(adypt_ctx *ctx, const adypt_pt_params *params);
+/* OglPathTracer::SetCamera (OglPathTracer.cpp:27-32) with the two inverses already taken (column-major, as glm). */
+int adypt_set_camera(adypt_ctx *ctx, const float origin[3], const float inv_proj[16], const float inv_view[16]);
+
+/* OglPathTracer::Trace(false): one primary-ray viewer frame (primaryray.glsl), viewer_type = ViewerTypes
+ * (OglPathTracer.hpp:20: 0 diffuse, 1 specular, 2 emissive, 4 normal, 5 position).  Resets the spp counter. */
+int adypt_trace_primary(adypt_ctx *ctx, int viewer_type);
+/* OglPathTracer::Trace(true), n_spp times: per frame Sobol::Next, spp++, wavefront passes.  The first call after
+ * adypt_reset()/adypt_trace_primary() clears the result image and restarts the Sobol sequence (OglPathTracer.cpp:39-46). */
+int adypt_trace_spp(adypt_ctx *ctx, int n_spp);
+int adypt_reset(adypt_ctx *ctx);
+int adypt_get_spp(const adypt_ctx *ctx); /* OglPathTracer::GetSPP */
+
+/* glGetTextureImage(m_result_tex, GL_RGB, GL_FLOAT) of OglPathTracer::SaveResult (OglPathTracer.cpp:203-205):
+ * W*H*3 floats, row 0 = top of the image.  Pixels of blocks this context does not own are left untouched. */
+int adypt_read_radiance(adypt_ctx *ctx, float *rgb);
+/* content of image 1 (uPrimaryTmpImg, pathtracer.glsl:114-127): scene triangle id and uv of the cached primary hit */
+int adypt_read_hits(adypt_ctx *ctx, int32_t *tri, float *uv);
+
+/* Trace an arbitrary batch of rays through the same traversal kernel: rays = n x 8 floats
+ * (ox, oy, oz, tmin, dx, dy, dz, unused).  with_stats selects the instrumented kernel variant. */
+int adypt_trace_rays(adypt_ctx *ctx, const float *rays, int64_t n, adypt_hit *hits, int with_stats);
+
+/* instrumentation: bit 0 = per-launch HIP-event timing, bit 1 = instrumented traversal (node/triangle counts) */
+int adypt_set_instrumentation(adypt_ctx *ctx, int flags);
+int adypt_get_stats(adypt_ctx *ctx, adypt_stats *out);
+int adypt_reset_stats(adypt_ctx *ctx);
+
+/* ---- pixel-tile sharding plumbing (multi-GPU: one context per GPU/process, one gather per output frame) ---- */
+/* number of RGBA float4 elements in the compact local radiance buffer (owned blocks x 1024 pixels) */
+int64_t adypt_local_pixel_count(const adypt_ctx *ctx);
+/* device pointer of the compact local radiance buffer (float4 per local pixel, block-major) */
+int adypt_local_radiance_device(adypt_ctx *ctx, void **dptr);
+/* blocks owned by `rank` out of `nranks` for a width x height image (same function the contexts use) */
+int64_t adypt_shard_block_count(int width, int height, int rank, int nranks);
+/* scatter one rank's compact buffer (host memory, block-major float4) into a W*H*3 host image */
+int adypt_untile_host(int width, int height, int rank, int nranks, const float *local_rgba, float *rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADYPT_HIP_H */

@@ -1,0 +1,86 @@
+/*
+ * adypt_host.h — C-ABI of the host-side pieces either side of the GPU path: the .config scene interface, OBJ/MTL
+ * scene loading, the CPU SBVH -> CWBVH8 builder and its .bvh cache, camera matrices, Sobol stream, EXR output.
+ * They reproduce what Instance::Initialize (src/Instance.cpp:10-42) strings together in the reference so that the
+ * tracer (adypt_hip.h) can run headless from an Adypt .config file.  None of these functions needs a GPU.
+ */
+#ifndef ADYPT_HOST_H
+#define ADYPT_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- InstanceConfig (src/InstanceConfig.hpp:12-48, src/InstanceConfig.cpp:10-192) ------------------------------ */
+typedef struct adypt_bvh_params { /* InstanceConfig::BVH; also the 12-byte header field of the .bvh cache */
+	int32_t max_spatial_depth;
+	float triangle_sah, node_sah;
+} adypt_bvh_params;
+
+typedef struct adypt_config {
+	int32_t width, height;
+	adypt_bvh_params bvh;
+	/* InstanceConfig::PT */
+	int32_t invocation_size, stack_size, max_bounce, subpixel, tmp_lifetime;
+	float ray_tmin, clamp, sun[3];
+	/* InstanceConfig::Cam */
+	float speed, mouse_sensitive, fov, yaw, pitch, position[3];
+	char obj_filename[1024], bvh_filename[1024];
+} adypt_config;
+
+void adypt_config_default(adypt_config *cfg);                       /* InstanceConfig::SetDefault */
+int adypt_config_load(const char *path, adypt_config *cfg);         /* InstanceConfig::LoadFromFile (strict: all keys, typed) */
+int adypt_config_parse(const char *json_text, adypt_config *cfg);
+/* InstanceConfig::GetJson: writes at most cap bytes incl. NUL, returns the needed size */
+size_t adypt_config_json(const adypt_config *cfg, char *buf, size_t cap);
+int adypt_config_save(const char *path, const adypt_config *cfg);   /* InstanceConfig::SaveToFile */
+const char *adypt_host_last_error(void);
+
+/* ---- Scene (src/Util/Scene.cpp:9-136) + material/texture conversion (src/Tracer/OglScene.cpp:12-91) ------------- */
+typedef struct adypt_scene adypt_scene;
+int adypt_scene_load(const char *obj_path, adypt_scene **out);      /* Scene::LoadFromFile + init_materials */
+void adypt_scene_free(adypt_scene *s);
+int64_t adypt_scene_triangles(const adypt_scene *s, const void **tris);   /* 100-byte records, OBJ order */
+int64_t adypt_scene_materials(const adypt_scene *s, const void **mats);   /* 64-byte GPUMaterial records */
+int32_t adypt_scene_textures(const adypt_scene *s, const void **tex /* adypt_texture[] */);
+void adypt_scene_aabb(const adypt_scene *s, float lo[3], float hi[3]);
+/* wrap caller-provided triangles (no OBJ): used for huge procedural scenes */
+int adypt_scene_from_arrays(const void *tris, int64_t n_tris, const void *mats, int64_t n_mats, adypt_scene **out);
+
+/* ---- BVH (src/BVH/SBVHBuilder.*, WideBVHBuilder.*, WideBVH.*) ---------------------------------------------------- */
+typedef struct adypt_bvh adypt_bvh;
+typedef struct adypt_build_info {
+	int64_t sbvh_nodes, refs, wide_nodes;
+	double sbvh_ms, wide_ms;
+} adypt_build_info;
+/* SBVHBuilder{cfg,&sbvh,scene}.Run(); WideBVHBuilder{cfg,&wbvh,sbvh}.Run(); (src/Instance.cpp:24-26) */
+int adypt_bvh_build(const adypt_scene *s, const adypt_bvh_params *p, adypt_bvh **out, adypt_build_info *info);
+int adypt_bvh_load(const char *path, const adypt_bvh_params *expected, adypt_bvh **out);  /* WideBVH::LoadFromFile */
+int adypt_bvh_save(const adypt_bvh *b, const char *path, const adypt_bvh_params *p);       /* WideBVH::SaveToFile */
+void adypt_bvh_free(adypt_bvh *b);
+int64_t adypt_bvh_nodes(const adypt_bvh *b, const void **nodes);          /* 80-byte records */
+int64_t adypt_bvh_tri_indices(const adypt_bvh *b, const int32_t **idx);
+
+/* ---- small restated host functions ---------------------------------------------------------------------------- */
+/* OglScene::init_triangles (src/Tracer/OglScene.cpp:93-116): out = 12 floats per reference */
+void adypt_woop_matrices(const void *tris, const int32_t *tri_indices, int64_t n_refs, float *out);
+/* Camera::GetView/GetProjection + the inverses of SetCamera (src/Tracer/Camera.cpp:13-23, OglPathTracer.cpp:27-32) */
+void adypt_camera_matrices(float fov, float yaw, float pitch, int width, int height, float inv_proj[16], float inv_view[16]);
+/* Sobol::Next (src/Util/Sobol.cpp:16-21): points of frames [first, first+n), dim <= 64; out = n*dim floats */
+int adypt_sobol_points(int dim, int first, int n, float *out);
+/* RG8 shift image bytes from mt19937(seed) (src/Tracer/OglPathTracer.cpp:156-162): width*height*2 bytes */
+void adypt_shift_bytes(uint32_t seed, int width, int height, uint8_t *out);
+/* SaveEXR(rgb, W, H, 3, fp16, path) as OglPathTracer::SaveResult calls it (OglPathTracer.cpp:207): scanline,
+ * ZIP, channels B,G,R, HALF or FLOAT */
+int adypt_save_exr(const char *path, const float *rgb, int width, int height, int save_as_fp16);
+/* minimal reader of the files adypt_save_exr writes (round-trip tests / tools) */
+int adypt_load_exr(const char *path, float **rgb, int *width, int *height);
+void adypt_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADYPT_HOST_H */
