@@ -1,0 +1,420 @@
+"""Host-side mirror of the reference's interface for the hot path, on top of the C-ABI.
+
+Names and call order follow the reference so that tests read like its own call sites:
+
+    InstanceConfig.LoadFromFile / GetJson / SaveToFile        src/InstanceConfig.cpp:10-210
+    Scene.LoadFromFile                                        src/Util/Scene.cpp:9-136
+    WideBVH.LoadFromFile / SaveToFile, build_bvh()            src/BVH/WideBVH.cpp:9-66, src/Instance.cpp:20-32
+    Camera.GetInvProjection / GetInvView                      src/Tracer/Camera.cpp:13-23 (+ inverses of SetCamera)
+    HipScene.Initialize(scene, bvh)                           OglScene::Initialize, src/Tracer/OglScene.hpp:43
+    HipPathTracer.Initialize / SetCamera / Trace / SaveResult / GetSPP
+                                                              OglPathTracer, src/Tracer/OglPathTracer.hpp:66-82
+    Instance.InitializeFromFile / Update                      src/Instance.cpp:10-69
+
+Everything numeric happens in libadypt_hip.so; this module only marshals numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+NODE_BYTES, TRI_BYTES, MAT_BYTES = 80, 100, 64
+HIT_DT = np.dtype([("ref_idx", "<i4"), ("tri_id", "<i4"), ("u", "<f4"), ("v", "<f4"), ("t", "<f4"),
+                   ("nodes", "<u4"), ("tris", "<u4"), ("hash", "<u4"), ("max_depth", "<u4")])
+
+
+def _bytes_view(ptr: int, n: int) -> np.ndarray:
+    if n == 0:
+        return np.zeros(0, dtype=np.uint8)
+    return np.frombuffer((C.c_char * n).from_address(ptr), dtype=np.uint8).copy()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class InstanceConfig:
+    """`.config` JSON <-> struct (src/InstanceConfig.hpp:12-48)."""
+
+    def __init__(self) -> None:
+        self.c = N.Config()
+        self.SetDefault()
+
+    def SetDefault(self) -> None:
+        N.lib.adypt_config_default(C.byref(self.c))
+
+    def LoadFromFile(self, filename: str) -> bool:
+        return N.lib.adypt_config_load(filename.encode(), C.byref(self.c)) == N.ADYPT_OK
+
+    def Parse(self, text: str) -> bool:
+        return N.lib.adypt_config_parse(text.encode(), C.byref(self.c)) == N.ADYPT_OK
+
+    def GetJson(self) -> str:
+        n = N.lib.adypt_config_json(C.byref(self.c), None, 0)
+        buf = C.create_string_buffer(n)
+        N.lib.adypt_config_json(C.byref(self.c), buf, n)
+        return buf.value.decode()
+
+    def SaveToFile(self, filename: str) -> bool:
+        return N.lib.adypt_config_save(filename.encode(), C.byref(self.c)) == N.ADYPT_OK
+
+    @staticmethod
+    def last_error() -> str:
+        return (N.lib.adypt_host_last_error() or b"").decode()
+
+    # convenient attribute access with the reference's member names
+    m_width = property(lambda s: s.c.width)
+    m_height = property(lambda s: s.c.height)
+    m_obj_filename = property(lambda s: s.c.obj_filename.decode())
+    m_bvh_filename = property(lambda s: s.c.bvh_filename.decode())
+
+    def pt_params(self, shift_seed: int = 0) -> N.PtParams:
+        p = N.PtParams()
+        p.stack_size, p.max_bounce, p.subpixel, p.tmp_lifetime = self.c.stack_size, self.c.max_bounce, self.c.subpixel, self.c.tmp_lifetime
+        p.ray_tmin, p.clamp = self.c.ray_tmin, self.c.clamp
+        p.sun[:] = list(self.c.sun)
+        p.shift_seed = shift_seed
+        return p
+
+    def bvh_params(self) -> N.BvhParams:
+        return N.BvhParams(self.c.bvh.max_spatial_depth, self.c.bvh.triangle_sah, self.c.bvh.node_sah)
+
+
+class Scene:
+    """Triangle[] + materials + decoded textures of an OBJ file."""
+
+    def __init__(self) -> None:
+        self._h = C.c_void_p()
+        self.triangles = np.zeros(0, dtype=np.uint8)
+        self.materials = np.zeros(0, dtype=np.uint8)
+        self.textures: List[np.ndarray] = []
+
+    def LoadFromFile(self, filename: str) -> bool:
+        self._free()
+        if N.lib.adypt_scene_load(filename.encode(), C.byref(self._h)) != N.ADYPT_OK:
+            return False
+        self._pull()
+        return True
+
+    @classmethod
+    def FromArrays(cls, triangles: np.ndarray, materials: np.ndarray) -> "Scene":
+        s = cls()
+        t = np.ascontiguousarray(triangles).view(np.uint8).reshape(-1)
+        m = np.ascontiguousarray(materials).view(np.uint8).reshape(-1)
+        N.check_host(N.lib.adypt_scene_from_arrays(t.ctypes.data, len(t) // TRI_BYTES, m.ctypes.data, len(m) // MAT_BYTES, C.byref(s._h)))
+        s._pull()
+        return s
+
+    def _pull(self) -> None:
+        p = C.c_void_p()
+        n = N.lib.adypt_scene_triangles(self._h, C.byref(p))
+        self.triangles = _bytes_view(p.value, n * TRI_BYTES)
+        n = N.lib.adypt_scene_materials(self._h, C.byref(p))
+        self.materials = _bytes_view(p.value, n * MAT_BYTES)
+        nt = N.lib.adypt_scene_textures(self._h, C.byref(p))
+        self.textures = []
+        if nt:
+            arr = (N.Texture * nt).from_address(p.value)
+            for t in arr:
+                self.textures.append(_bytes_view(t.rgb, t.width * t.height * 3).reshape(t.height, t.width, 3))
+
+    def GetTriangles(self) -> np.ndarray:
+        return self.triangles
+
+    def GetMaterials(self) -> np.ndarray:
+        return self.materials
+
+    def GetAABB(self) -> Tuple[np.ndarray, np.ndarray]:
+        lo = np.zeros(3, dtype=np.float32)
+        hi = np.zeros(3, dtype=np.float32)
+        N.lib.adypt_scene_aabb(self._h, lo.ctypes.data, hi.ctypes.data)
+        return lo, hi
+
+    @property
+    def n_tris(self) -> int:
+        return len(self.triangles) // TRI_BYTES
+
+    def _free(self) -> None:
+        if self._h:
+            N.lib.adypt_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self) -> None:
+        try:
+            self._free()
+        except Exception:
+            pass
+
+
+class WideBVH:
+    """80-byte CWBVH8 nodes + reference->triangle indices (src/BVH/WideBVH.hpp:28-43)."""
+
+    def __init__(self) -> None:
+        self._h = C.c_void_p()
+        self.nodes = np.zeros(0, dtype=np.uint8)
+        self.tri_indices = np.zeros(0, dtype=np.int32)
+        self.build_info: Optional[N.BuildInfo] = None
+
+    def _pull(self) -> None:
+        p = C.c_void_p()
+        n = N.lib.adypt_bvh_nodes(self._h, C.byref(p))
+        self.nodes = _bytes_view(p.value, n * NODE_BYTES)
+        n = N.lib.adypt_bvh_tri_indices(self._h, C.byref(p))
+        self.tri_indices = _bytes_view(p.value, n * 4).view(np.int32)
+
+    def LoadFromFile(self, filename: str, expected: N.BvhParams) -> bool:
+        self._free()
+        if N.lib.adypt_bvh_load(filename.encode(), C.byref(expected), C.byref(self._h)) != N.ADYPT_OK:
+            return False
+        self._pull()
+        return True
+
+    def SaveToFile(self, filename: str, cfg: N.BvhParams) -> bool:
+        return N.lib.adypt_bvh_save(self._h, filename.encode(), C.byref(cfg)) == N.ADYPT_OK
+
+    def Build(self, scene: Scene, cfg: N.BvhParams) -> None:
+        """SBVHBuilder{cfg,&sbvh,scene}.Run(); WideBVHBuilder{cfg,&wbvh,sbvh}.Run() (src/Instance.cpp:24-26)."""
+        self._free()
+        info = N.BuildInfo()
+        N.check_host(N.lib.adypt_bvh_build(scene._h, C.byref(cfg), C.byref(self._h), C.byref(info)))
+        self.build_info = info
+        self._pull()
+
+    def GetNodes(self) -> np.ndarray:
+        return self.nodes
+
+    def GetTriIndices(self) -> np.ndarray:
+        return self.tri_indices
+
+    def _free(self) -> None:
+        if self._h:
+            N.lib.adypt_bvh_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self) -> None:
+        try:
+            self._free()
+        except Exception:
+            pass
+
+
+def woop_matrices(triangles: np.ndarray, tri_indices: np.ndarray) -> np.ndarray:
+    t = np.ascontiguousarray(triangles).view(np.uint8).reshape(-1)
+    idx = np.ascontiguousarray(tri_indices, dtype=np.int32)
+    out = np.empty((len(idx), 12), dtype=np.float32)
+    N.lib.adypt_woop_matrices(t.ctypes.data, idx.ctypes.data, len(idx), out.ctypes.data)
+    return out
+
+
+def sobol_points(dim: int, first: int, n: int) -> np.ndarray:
+    out = np.empty((n, dim), dtype=np.float32)
+    N.check_host(N.lib.adypt_sobol_points(dim, first, n, out.ctypes.data))
+    return out
+
+
+def shift_bytes(seed: int, width: int, height: int) -> np.ndarray:
+    out = np.empty((height, width, 2), dtype=np.uint8)
+    N.lib.adypt_shift_bytes(seed, width, height, out.ctypes.data)
+    return out
+
+
+def save_exr(path: str, rgb: np.ndarray, save_as_fp16: bool = False) -> None:
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w = rgb.shape[:2]
+    N.check_host(N.lib.adypt_save_exr(path.encode(), rgb.ctypes.data, w, h, 1 if save_as_fp16 else 0))
+
+
+def load_exr(path: str) -> np.ndarray:
+    p = C.c_void_p()
+    w = C.c_int()
+    h = C.c_int()
+    N.check_host(N.lib.adypt_load_exr(path.encode(), C.byref(p), C.byref(w), C.byref(h)))
+    out = np.frombuffer((C.c_float * (w.value * h.value * 3)).from_address(p.value), dtype=np.float32).copy().reshape(h.value, w.value, 3)
+    N.lib.adypt_free(p)
+    return out
+
+
+class Camera:
+    """Camera::Initialize / GetView / GetProjection (src/Tracer/Camera.hpp:27-36); Control() is out of scope."""
+
+    def Initialize(self, cfg: InstanceConfig, width: int, height: int) -> None:
+        self.cfg, self.width, self.height = cfg, width, height
+
+    def matrices(self) -> Tuple[np.ndarray, np.ndarray]:
+        ip = np.empty(16, dtype=np.float32)
+        iv = np.empty(16, dtype=np.float32)
+        c = self.cfg.c
+        N.lib.adypt_camera_matrices(c.fov, c.yaw, c.pitch, self.width, self.height, ip.ctypes.data, iv.ctypes.data)
+        return ip, iv
+
+    @property
+    def position(self) -> np.ndarray:
+        return np.array(list(self.cfg.c.position), dtype=np.float32)
+
+
+def camera_matrices(fov: float, yaw: float, pitch: float, width: int, height: int) -> Tuple[np.ndarray, np.ndarray]:
+    ip = np.empty(16, dtype=np.float32)
+    iv = np.empty(16, dtype=np.float32)
+    N.lib.adypt_camera_matrices(fov, yaw, pitch, width, height, ip.ctypes.data, iv.ctypes.data)
+    return ip, iv
+
+
+class HipScene:
+    """OglScene: the flat arrays the kernels consume.  Initialize(scene, bvh) only records host arrays; the upload
+    to HBM happens in HipPathTracer.Initialize (adypt_create) because the C-ABI creates scene + images together."""
+
+    def Initialize(self, scene: Scene, bvh: WideBVH, woop: Optional[np.ndarray] = None) -> None:
+        self.scene, self.bvh = scene, bvh
+        self.woop = None if woop is None else np.ascontiguousarray(woop, dtype=np.float32)
+
+    def GetTextures(self) -> Sequence[np.ndarray]:
+        return self.scene.textures
+
+
+class ViewerTypes:
+    kDiffuse, kSpecular, kEmissive, kPTRadiance, kNormal, kPosition = range(6)
+
+
+class HipPathTracer:
+    """OglPathTracer (src/Tracer/OglPathTracer.hpp:66-82) on HIP."""
+
+    def __init__(self) -> None:
+        self._ctx = C.c_void_p()
+        self.m_viewer_type = ViewerTypes.kDiffuse
+
+    def Initialize(self, config: N.PtParams, scene: HipScene, width: int, height: int, device: int = 0,
+                   tile_rank: int = 0, tile_nranks: int = 1) -> None:
+        self.destroy()
+        self.width, self.height = width, height
+        s, b = scene.scene, scene.bvh
+        tex_arr = (N.Texture * max(1, len(s.textures)))()
+        self._keep = [s.triangles, s.materials, b.nodes, b.tri_indices, scene.woop, tex_arr] + list(s.textures)
+        for i, t in enumerate(s.textures):
+            tex_arr[i].width, tex_arr[i].height, tex_arr[i].rgb = t.shape[1], t.shape[0], t.ctypes.data
+        d = N.SceneDesc()
+        d.nodes, d.n_nodes = b.nodes.ctypes.data, len(b.nodes) // NODE_BYTES
+        d.tri_indices, d.n_refs = b.tri_indices.ctypes.data, len(b.tri_indices)
+        d.woop = None if scene.woop is None else scene.woop.ctypes.data
+        d.triangles, d.n_tris = s.triangles.ctypes.data, len(s.triangles) // TRI_BYTES
+        d.materials, d.n_mats = (s.materials.ctypes.data if len(s.materials) else None), len(s.materials) // MAT_BYTES
+        d.textures, d.n_textures = (C.addressof(tex_arr) if s.textures else None), len(s.textures)
+        d.width, d.height, d.device, d.tile_rank, d.tile_nranks = width, height, device, tile_rank, tile_nranks
+        N.check(N.lib.adypt_create(C.byref(self._ctx), C.byref(d)))
+        self.SetConfig(config)
+
+    def SetConfig(self, config: N.PtParams) -> None:
+        N.check(N.lib.adypt_set_params(self._ctx, C.byref(config)), self._ctx)
+
+    def SetCamera(self, inv_projection: np.ndarray, inv_view: np.ndarray, position) -> None:
+        ip = np.ascontiguousarray(inv_projection, dtype=np.float32).reshape(16)
+        iv = np.ascontiguousarray(inv_view, dtype=np.float32).reshape(16)
+        pos = np.ascontiguousarray(position, dtype=np.float32).reshape(3)
+        N.check(N.lib.adypt_set_camera(self._ctx, pos.ctypes.data, ip.ctypes.data, iv.ctypes.data), self._ctx)
+
+    def Trace(self, enable_pt: bool, n_spp: int = 1) -> None:
+        """Trace(true): n_spp more frames; Trace(false): one primary-ray viewer frame of m_viewer_type."""
+        if enable_pt:
+            self.m_viewer_type = ViewerTypes.kPTRadiance
+            N.check(N.lib.adypt_trace_spp(self._ctx, n_spp), self._ctx)
+        else:
+            if self.m_viewer_type == ViewerTypes.kPTRadiance:
+                self.m_viewer_type = ViewerTypes.kDiffuse
+            N.check(N.lib.adypt_trace_primary(self._ctx, self.m_viewer_type), self._ctx)
+
+    def Reset(self) -> None:
+        N.check(N.lib.adypt_reset(self._ctx), self._ctx)
+
+    def GetSPP(self) -> int:
+        return N.lib.adypt_get_spp(self._ctx)
+
+    def ReadResult(self) -> np.ndarray:
+        rgb = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        N.check(N.lib.adypt_read_radiance(self._ctx, rgb.ctypes.data), self._ctx)
+        return rgb
+
+    def ReadHits(self) -> Tuple[np.ndarray, np.ndarray]:
+        tri = np.full((self.height, self.width), -1, dtype=np.int32)
+        uv = np.zeros((self.height, self.width, 2), dtype=np.float32)
+        N.check(N.lib.adypt_read_hits(self._ctx, tri.ctypes.data, uv.ctypes.data), self._ctx)
+        return tri, uv
+
+    def SaveResult(self, filename: str, save_as_fp16: bool) -> None:
+        save_exr(filename, self.ReadResult(), save_as_fp16)
+
+    def TraceRays(self, rays: np.ndarray, with_stats: bool = True) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        hits = np.zeros(len(rays), dtype=HIT_DT)
+        N.check(N.lib.adypt_trace_rays(self._ctx, rays.ctypes.data, len(rays), hits.ctypes.data, 1 if with_stats else 0), self._ctx)
+        return hits
+
+    def SetInstrumentation(self, timing: bool = False, counters: bool = False) -> None:
+        N.check(N.lib.adypt_set_instrumentation(self._ctx, (1 if timing else 0) | (2 if counters else 0)), self._ctx)
+
+    def GetStats(self) -> dict:
+        st = N.Stats()
+        N.check(N.lib.adypt_get_stats(self._ctx, C.byref(st)), self._ctx)
+        return st.as_dict()
+
+    def ResetStats(self) -> None:
+        N.check(N.lib.adypt_reset_stats(self._ctx), self._ctx)
+
+    def local_pixel_count(self) -> int:
+        return N.lib.adypt_local_pixel_count(self._ctx)
+
+    def local_radiance_device_ptr(self) -> int:
+        p = C.c_void_p()
+        N.check(N.lib.adypt_local_radiance_device(self._ctx, C.byref(p)), self._ctx)
+        return p.value
+
+    def destroy(self) -> None:
+        if self._ctx:
+            N.lib.adypt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self) -> None:
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Instance:
+    """Headless Instance (src/Instance.cpp): config -> scene -> (.bvh cache | build) -> upload -> tracer -> camera."""
+
+    def __init__(self) -> None:
+        self.m_config = InstanceConfig()
+        self.m_path_tracer = HipPathTracer()
+        self.m_hipscene = HipScene()
+        self.m_camera = Camera()
+        self.m_valid = False
+
+    def InitializeFromFile(self, filename: str, shift_seed: int = 12345, device: int = 0, tile_rank: int = 0,
+                           tile_nranks: int = 1) -> bool:
+        self.m_filename = filename
+        if not self.m_config.LoadFromFile(filename):
+            return False
+        return self.Initialize(shift_seed, device, tile_rank, tile_nranks)
+
+    def Initialize(self, shift_seed: int = 12345, device: int = 0, tile_rank: int = 0, tile_nranks: int = 1) -> bool:
+        cfg = self.m_config
+        self.scene = Scene()
+        if not self.scene.LoadFromFile(cfg.m_obj_filename):
+            return False
+        self.bvh = WideBVH()
+        bp = cfg.bvh_params()
+        if not self.bvh.LoadFromFile(cfg.m_bvh_filename, bp):
+            self.bvh.Build(self.scene, bp)
+            if not self.bvh.SaveToFile(cfg.m_bvh_filename, bp):
+                return False
+        self.m_hipscene.Initialize(self.scene, self.bvh)
+        self.m_path_tracer.Initialize(cfg.pt_params(shift_seed), self.m_hipscene, cfg.m_width, cfg.m_height, device, tile_rank, tile_nranks)
+        self.m_camera.Initialize(cfg, cfg.m_width, cfg.m_height)
+        ip, iv = self.m_camera.matrices()
+        self.m_path_tracer.SetCamera(ip, iv, self.m_camera.position)
+        self.m_valid = True
+        return True
+
+    def Update(self, enable_pt: bool, n_spp: int = 1) -> None:
+        self.m_path_tracer.Trace(enable_pt, n_spp)

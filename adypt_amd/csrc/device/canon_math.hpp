@@ -1,0 +1,136 @@
+// Canonical arithmetic of the tracer (device side).
+//
+// GLSL leaves the rounding of normalize / dot / 1/x / pow / sin / cos and fma contraction to the driver, so the
+// build pins one arithmetic and implements it twice, independently: here for gfx950 and in oracle/oracle.cpp for
+// the CPU checker.  The rules (DESIGN.md "Canonical arithmetic"):
+//   * binary32 IEEE-754 round-to-nearest-even + - * / sqrt in the written order (hipcc: -ffp-contract=off,
+//     correctly rounded fp32 divide/sqrt are the HIP default);
+//   * fused multiply-add only where fmaf()/fma() is written;
+//   * dot3(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x)); normalize(v) = v * (1/sqrt(dot3(v,v)));
+//   * sin/cos/pow = fixed binary64 series below, rounded once to binary32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace adypt {
+
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ F3 fma3(F3 a, float s, F3 c) { return f3(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z)); }
+__device__ __forceinline__ F3 fma3(F3 a, F3 b, F3 c) { return f3(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z)); }
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b)
+{
+	return f3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ F3 normalize3(F3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return a * inv; }
+__device__ __forceinline__ F3 reflect3(F3 i, F3 n) { float k = 2.0f * dot3(n, i); return fma3(n, -k, i); }
+// GLSL min/max NaN rule
+__device__ __forceinline__ float gl_min(float x, float y) { return y < x ? y : x; }
+__device__ __forceinline__ float gl_max(float x, float y) { return x < y ? y : x; }
+
+__device__ inline void canon_sincos(float xf, float *s_out, float *c_out)
+{
+	const double TWO_OVER_PI = 0.63661977236758134308;
+	const double PIO2_HI = 1.57079632679489655800e+00;
+	const double PIO2_LO = 6.12323399573676603587e-17;
+	double x = (double)xf;
+	double kd = rint(x * TWO_OVER_PI);
+	double y = fma(-kd, PIO2_HI, x);
+	y = fma(-kd, PIO2_LO, y);
+	double y2 = y * y;
+	double ps = -1.0 / 121645100408832000.0;
+	ps = fma(ps, y2, 1.0 / 355687428096000.0);
+	ps = fma(ps, y2, -1.0 / 1307674368000.0);
+	ps = fma(ps, y2, 1.0 / 6227020800.0);
+	ps = fma(ps, y2, -1.0 / 39916800.0);
+	ps = fma(ps, y2, 1.0 / 362880.0);
+	ps = fma(ps, y2, -1.0 / 5040.0);
+	ps = fma(ps, y2, 1.0 / 120.0);
+	ps = fma(ps, y2, -1.0 / 6.0);
+	double sn = fma(y * y2, ps, y);
+	double pc = 1.0 / 2432902008176640000.0;
+	pc = fma(pc, y2, -1.0 / 6402373705728000.0);
+	pc = fma(pc, y2, 1.0 / 20922789888000.0);
+	pc = fma(pc, y2, -1.0 / 87178291200.0);
+	pc = fma(pc, y2, 1.0 / 479001600.0);
+	pc = fma(pc, y2, -1.0 / 3628800.0);
+	pc = fma(pc, y2, 1.0 / 40320.0);
+	pc = fma(pc, y2, -1.0 / 720.0);
+	pc = fma(pc, y2, 1.0 / 24.0);
+	pc = fma(pc, y2, -0.5);
+	double cs = fma(y2, pc, 1.0);
+	long long k = (long long)kd;
+	double s, c;
+	switch(k & 3)
+	{
+		case 0: s = sn; c = cs; break;
+		case 1: s = cs; c = -sn; break;
+		case 2: s = -sn; c = -cs; break;
+		default: s = -cs; c = sn; break;
+	}
+	*s_out = (float)s;
+	*c_out = (float)c;
+}
+
+__device__ inline float canon_pow(float xf, float yf)
+{
+	if(yf == 0.0f) return 1.0f;
+	if(xf != xf || yf != yf) return xf + yf;
+	if(xf < 0.0f) return __uint_as_float(0x7fc00000u);
+	if(xf == 0.0f) return yf > 0.0f ? 0.0f : __uint_as_float(0x7f800000u);
+	if(xf == __uint_as_float(0x7f800000u)) return yf > 0.0f ? xf : 0.0f;
+	double x = (double)xf;
+	unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+	int e = (int)((bits >> 52) & 0x7ff) - 1023;
+	bits = (bits & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+	double m = __longlong_as_double((long long)bits);
+	if(m > 1.41421356237309514547) { m *= 0.5; e += 1; }
+	double s = (m - 1.0) / (m + 1.0);
+	double s2 = s * s;
+	double p = 1.0 / 23.0;
+	p = fma(p, s2, 1.0 / 21.0);
+	p = fma(p, s2, 1.0 / 19.0);
+	p = fma(p, s2, 1.0 / 17.0);
+	p = fma(p, s2, 1.0 / 15.0);
+	p = fma(p, s2, 1.0 / 13.0);
+	p = fma(p, s2, 1.0 / 11.0);
+	p = fma(p, s2, 1.0 / 9.0);
+	p = fma(p, s2, 1.0 / 7.0);
+	p = fma(p, s2, 1.0 / 5.0);
+	p = fma(p, s2, 1.0 / 3.0);
+	double ln_m = 2.0 * fma(s * s2, p, s);
+	const double LOG2E = 1.44269504088896338700;
+	double log2x = fma(ln_m, LOG2E, (double)e);
+	double t = (double)yf * log2x;
+	if(t >= 129.0) return __uint_as_float(0x7f800000u);
+	if(t <= -151.0) return 0.0f;
+	double n = rint(t);
+	double f = t - n;
+	const double LN2 = 0.69314718055994528623;
+	double z = f * LN2;
+	double q = 1.0 / 6227020800.0;
+	q = fma(q, z, 1.0 / 479001600.0);
+	q = fma(q, z, 1.0 / 39916800.0);
+	q = fma(q, z, 1.0 / 3628800.0);
+	q = fma(q, z, 1.0 / 362880.0);
+	q = fma(q, z, 1.0 / 40320.0);
+	q = fma(q, z, 1.0 / 5040.0);
+	q = fma(q, z, 1.0 / 720.0);
+	q = fma(q, z, 1.0 / 120.0);
+	q = fma(q, z, 1.0 / 24.0);
+	q = fma(q, z, 1.0 / 6.0);
+	q = fma(q, z, 0.5);
+	q = fma(q, z, 1.0);
+	q = fma(q, z, 1.0);
+	unsigned long long sb = (unsigned long long)((long long)n + 1023) << 52;
+	double scale = __longlong_as_double((long long)sb);
+	return (float)(q * scale);
+}
+
+}  // namespace adypt

@@ -1,0 +1,650 @@
+// gfx950 kernels of the wavefront path tracer.
+//
+//   k_trace<STATS>      persistent wave64 CWBVH8 closest-hit traversal  (shaders/traversal.glsl:14-255)
+//   k_gen_primary       camera rays + path-state init                   (shaders/pathtracer.glsl:206-224, primaryray.glsl:39-49)
+//   k_shade             one bounce of Render(): FetchInfo, scatter, compaction, accumulate on termination
+//                                                                       (shaders/pathtracer.glsl:73-204,224-226)
+//   k_viewer            primary-ray viewer colouring                    (shaders/primaryray.glsl:50-94)
+//   k_untile            compact block-major radiance -> W x H RGB
+//
+// Queue layout (SoA of float4, slot-indexed, rewritten compacted every bounce):
+//   ray_o = (origin.xyz, tmin)      ray_d = (dir.xyz, bits(local pixel))      <- the 32 B the traversal reads
+//   col   = (throughput rgb, -)     rad   = (radiance so far rgb, -)          <- carried by the shade kernel only
+//   hit   = (bits(scene triangle id), u, v, t)                                 <- the 16 B the traversal writes
+// Per-local-pixel buffers (block-major, 32x32 blocks of 16 8x8 wave tiles): accum (RGBA32F running mean),
+// cache (primary hit: bits(tri), u, v, -), shift (2 bytes).
+#pragma once
+#include "canon_math.hpp"
+
+namespace adypt {
+
+constexpr int kBlockShift = 5;                 // 32x32 pixel shard blocks
+constexpr int kBlockDim = 1 << kBlockShift;
+constexpr int kBlockPixels = kBlockDim * kBlockDim;
+constexpr int kTraceThreads = 256;             // 4 waves per workgroup
+constexpr int kLdsStackMax = 16;               // stack entries kept in LDS per lane; deeper entries spill to HBM
+constexpr int kNumSegments = 8;                // one ray-queue segment per XCD
+
+struct DeviceCounters {                        // zeroed at the start of every frame / batch
+	uint32_t queue_count[2];                   // live rays in queue A / B
+	uint32_t cursor[2][kNumSegments];          // persistent-fetch cursors per queue parity
+	uint32_t pad[14];
+};
+
+struct DeviceStats {                           // accumulated until adypt_reset_stats
+	unsigned long long rays, nodes, tris, hits, shaded, overflows, bad_materials;
+	uint32_t max_stack, pad;
+};
+
+struct RayStats { int32_t ref_idx; uint32_t nodes, tris, hash, max_depth, pad0, pad1, pad2; }; // 32 B, STATS variant
+
+struct TraceArgs {
+	const uint4 *nodes;
+	const float4 *woop;
+	const int32_t *tri_indices;
+	const float4 *ray_o, *ray_d;
+	float4 *hit;
+	RayStats *ray_stats;           // STATS only (may be null)
+	const uint32_t *count;         // number of rays in the queue (device memory)
+	uint32_t *cursor;              // kNumSegments cursors, zero at launch
+	uint2 *spill;                  // [(stack_size - lds_depth)][total lanes]
+	DeviceStats *stats;
+	int32_t stack_size, lds_depth;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// persistent ray fetch: the queue is cut into kNumSegments contiguous segments (multiples of 64 rays); a workgroup
+// first drains the segment of "its" XCD (workgroups are dealt round-robin over the 8 XCDs, so blockIdx & 7 groups
+// the workgroups that share an L2 — a speed hint only, never needed for correctness), then steals from the others.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool fetch_batch(uint32_t *cursor, uint32_t count, uint32_t seg_size, int home, uint32_t *begin, uint32_t *end)
+{
+	for(int k = 0; k < kNumSegments; ++k)
+	{
+		const int s = (home + k) & (kNumSegments - 1);
+		const uint32_t seg_begin = min((uint32_t)s * seg_size, count);
+		const uint32_t seg_end = min(seg_begin + seg_size, count);
+		if(seg_begin >= seg_end) continue;
+		// cheap pre-check keeps exhausted segments from being hammered with atomics
+		if(__hip_atomic_load(&cursor[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seg_end - seg_begin) continue;
+		const uint32_t rel = atomicAdd(&cursor[s], 64u);
+		if(rel < seg_end - seg_begin)
+		{
+			*begin = seg_begin + rel;
+			*end = min(seg_begin + rel + 64u, seg_end);
+			return true;
+		}
+	}
+	return false;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
+{
+	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64]
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
+	const uint32_t total_lanes = gridDim.x * blockDim.x;
+	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+
+	const uint32_t count = *a.count;
+	const uint32_t seg_size = (((count + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
+	const int home = blockIdx.x & (kNumSegments - 1);
+
+	if(blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats->rays, (unsigned long long)count);
+
+	unsigned long long st_nodes = 0, st_tris = 0, st_hits = 0;
+	uint32_t st_maxdepth = 0;
+	bool any_overflow = false;
+
+	for(;;)
+	{
+		uint32_t b = 0, e = 0;
+		int got = 0;
+		if(lane == 0) got = fetch_batch(a.cursor, count, seg_size, home, &b, &e) ? 1 : 0;
+		got = __builtin_amdgcn_readfirstlane(got);
+		if(!got) break;
+		b = __builtin_amdgcn_readfirstlane(b);
+		e = __builtin_amdgcn_readfirstlane(e);
+		const uint32_t ray = b + lane;
+		if(ray >= e) continue;
+
+		// ---- ray setup (traversal.glsl:16-29) ----
+		const float4 ro = a.ray_o[ray];
+		const float4 rd = a.ray_d[ray];
+		const float ooeps = __uint_as_float((127u - 64u) << 23);
+		F3 dir = f3(rd.x, rd.y, rd.z);
+		dir.x = fabsf(dir.x) > ooeps ? dir.x : (dir.x >= 0 ? ooeps : -ooeps);
+		dir.y = fabsf(dir.y) > ooeps ? dir.y : (dir.y >= 0 ? ooeps : -ooeps);
+		dir.z = fabsf(dir.z) > ooeps ? dir.z : (dir.z >= 0 ? ooeps : -ooeps);
+		dir = normalize3(dir);
+		const F3 idir = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+		const bool nx = dir.x < 0, ny = dir.y < 0, nz = dir.z < 0;
+		const uint32_t octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
+		const uint32_t octinv4 = octinv * 0x01010101u;
+		const F3 origin = f3(ro.x, ro.y, ro.z);
+		const float tmin = ro.w;
+		float hit_t = 1e9f, hit_u = 0.0f, hit_v = 0.0f;
+		int32_t hit_idx = -1;
+
+		int sp = 0;
+		uint32_t ng_x = 0, ng_y = 0x80000000u, tg_x = 0, tg_y = 0;
+		uint32_t n_nodes = 0, n_tris = 0, hash = 0x811c9dc5u, max_depth = 0;
+		bool overflow = false;
+
+		for(;;)
+		{
+			if(ng_y > 0x00ffffffu)
+			{
+				const uint32_t imask = ng_y;
+				const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng_y);
+				const uint32_t base = ng_x;
+				ng_y &= ~(1u << bit);
+				if(ng_y > 0x00ffffffu)
+				{
+					if(sp < a.stack_size)
+					{
+						if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);
+						else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);
+						++sp;
+						if(STATS) max_depth = max(max_depth, (uint32_t)sp);
+					}
+					else overflow = true;
+				}
+				const uint32_t slot = (bit - 24u) ^ octinv;
+				const uint32_t rel = (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
+				const uint32_t node = base + rel;
+
+				const uint4 *np = a.nodes + (size_t)node * 5;
+				const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+				if(STATS) { ++n_nodes; hash = (hash * 0x01000193u) ^ node; }
+
+				const uint32_t head_w = n0.w;
+				const float aix = __uint_as_float((head_w & 0xffu) << 23) * idir.x;
+				const float aiy = __uint_as_float(((head_w >> 8) & 0xffu) << 23) * idir.y;
+				const float aiz = __uint_as_float(((head_w >> 16) & 0xffu) << 23) * idir.z;
+				const float aox = (__uint_as_float(n0.x) - origin.x) * idir.x;
+				const float aoy = (__uint_as_float(n0.y) - origin.y) * idir.y;
+				const float aoz = (__uint_as_float(n0.z) - origin.z) * idir.z;
+
+				ng_x = n1.x;
+				tg_x = n1.y;
+				uint32_t hitmask = 0;
+#pragma unroll
+				for(int g = 0; g < 2; ++g)
+				{
+					const uint32_t meta4 = g ? n1.w : n1.z;
+					const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+					const uint32_t bit_index4 = (meta4 ^ (octinv4 & ((is_inner4 >> 4) * 0xffu))) & 0x1f1f1f1fu;
+					const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+					const uint32_t qlox = g ? n2.y : n2.x, qloy = g ? n2.w : n2.z, qloz = g ? n3.y : n3.x;
+					const uint32_t qhix = g ? n3.w : n3.z, qhiy = g ? n4.y : n4.x, qhiz = g ? n4.w : n4.z;
+					const uint32_t slox = nx ? qhix : qlox, shix = nx ? qlox : qhix;
+					const uint32_t sloy = ny ? qhiy : qloy, shiy = ny ? qloy : qhiy;
+					const uint32_t sloz = nz ? qhiz : qloz, shiz = nz ? qloz : qhiz;
+#pragma unroll
+					for(int j = 0; j < 4; ++j)
+					{
+						const int sh = 8 * j;
+						const float txmin = fmaf((float)((slox >> sh) & 0xffu), aix, aox);
+						const float tymin = fmaf((float)((sloy >> sh) & 0xffu), aiy, aoy);
+						const float tzmin = fmaf((float)((sloz >> sh) & 0xffu), aiz, aoz);
+						const float txmax = fmaf((float)((shix >> sh) & 0xffu), aix, aox);
+						const float tymax = fmaf((float)((shiy >> sh) & 0xffu), aiy, aoy);
+						const float tzmax = fmaf((float)((shiz >> sh) & 0xffu), aiz, aoz);
+						// no NaN can reach these (finite node data, |idir| <= 2^64): hardware max/min == GLSL max/min
+						const float cmin = fmaxf(fmaxf(txmin, tymin), fmaxf(tzmin, tmin));
+						const float cmax = fminf(fminf(txmax, tymax), fminf(tzmax, hit_t));
+						if(cmin <= cmax) hitmask |= ((child_bits4 >> sh) & 0xffu) << ((bit_index4 >> sh) & 0xffu);
+					}
+				}
+				ng_y = (hitmask & 0xff000000u) | (head_w >> 24);
+				tg_y = hitmask & 0x00ffffffu;
+			}
+			else
+			{
+				tg_x = ng_x; tg_y = ng_y;
+				ng_x = 0; ng_y = 0;
+			}
+
+			while(tg_y != 0)
+			{
+				const uint32_t tb = (uint32_t)__builtin_ctz(tg_y);
+				tg_y &= ~(1u << tb);
+				const uint32_t tri = tg_x + tb;
+				const float4 *wp = a.woop + (size_t)tri * 3;
+				const float4 m0 = wp[0], m1 = wp[1], m2 = wp[2];
+				if(STATS) ++n_tris;
+				const float toz = m0.w - dot3(origin, f3(m0.x, m0.y, m0.z));
+				const float tidz = 1.0f / dot3(dir, f3(m0.x, m0.y, m0.z));
+				const float tt = toz * tidz;
+				const float tox = m1.w + dot3(origin, f3(m1.x, m1.y, m1.z));
+				const float tdx = dot3(dir, f3(m1.x, m1.y, m1.z));
+				const float tu = fmaf(tt, tdx, tox);
+				const float toy = m2.w + dot3(origin, f3(m2.x, m2.y, m2.z));
+				const float tdy = dot3(dir, f3(m2.x, m2.y, m2.z));
+				const float tv = fmaf(tt, tdy, toy);
+				if(tt > tmin && tt < hit_t && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f)
+				{
+					hit_t = tt; hit_u = tu; hit_v = tv; hit_idx = (int32_t)tri;
+				}
+			}
+
+			if(ng_y <= 0x00ffffffu)
+			{
+				if(sp == 0) break;
+				--sp;
+				const uint2 g = sp < a.lds_depth ? my_stack[sp * 64] : my_spill[(size_t)(sp - a.lds_depth) * total_lanes];
+				ng_x = g.x; ng_y = g.y;
+			}
+		}
+
+		const int32_t tri_id = hit_idx != -1 ? a.tri_indices[hit_idx] : -1;
+		a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
+		any_overflow |= overflow;
+		if(STATS)
+		{
+			if(a.ray_stats)
+			{
+				RayStats rs;
+				rs.ref_idx = hit_idx; rs.nodes = n_nodes; rs.tris = n_tris; rs.hash = hash;
+				rs.max_depth = overflow ? 0xffffffffu : max_depth; rs.pad0 = rs.pad1 = rs.pad2 = 0;
+				a.ray_stats[ray] = rs;
+			}
+			st_nodes += n_nodes; st_tris += n_tris; st_hits += hit_idx != -1 ? 1 : 0;
+			st_maxdepth = max(st_maxdepth, max_depth);
+		}
+	}
+
+	if(any_overflow) atomicAdd(&a.stats->overflows, 1ull);
+	if(STATS)
+	{
+		// wave reduction, then one atomic per wave
+		for(int off = 32; off > 0; off >>= 1)
+		{
+			st_nodes += __shfl_down(st_nodes, off);
+			st_tris += __shfl_down(st_tris, off);
+			st_hits += __shfl_down(st_hits, off);
+			st_maxdepth = max(st_maxdepth, (uint32_t)__shfl_down((int)st_maxdepth, off));
+		}
+		if(lane == 0)
+		{
+			atomicAdd(&a.stats->nodes, st_nodes);
+			atomicAdd(&a.stats->tris, st_tris);
+			atomicAdd(&a.stats->hits, st_hits);
+			atomicMax(&a.stats->max_stack, st_maxdepth);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// frame-level parameters (uuCamera + uuPT UBOs of the reference, plus shard geometry)
+// ---------------------------------------------------------------------------------------------------------------
+struct FrameArgs {
+	float inv_proj[16], inv_view[16];
+	float origin[3], tmin;
+	float sun[3], clamp;
+	float sobol[64];               // this frame's Sobol point: 2*max_bounce floats (pathtracer.glsl:46,49)
+	int32_t width, height;
+	int32_t spp, subpixel, tmp_life, max_bounce;
+	int32_t n_local_px;            // owned blocks * 1024
+	int32_t blocks_x;              // image width in 32-px blocks
+	int32_t rank, nranks;
+	int32_t n_tris, n_mats, n_tex;
+};
+
+struct SceneArgs {
+	const float *triangles;        // 25 floats per triangle
+	const float4 *materials;       // 4 x float4 per material
+	const uint32_t *texels;        // RGBA8, all textures back to back
+	const int4 *tex_desc;          // (offset, w, h, 0) per texture
+	const int32_t *local_blocks;   // global block id of each owned block
+};
+
+struct QueueArgs {
+	float4 *ray_o, *ray_d, *col, *rad;   // queue being read (shade) / written (gen)
+	float4 *hit;
+	float4 *out_o, *out_d, *out_col, *out_rad;
+	const uint32_t *count_in;
+	uint32_t *count_out;
+};
+
+struct PixelArgs {
+	float4 *accum;                 // running mean RGBA per local pixel   (image 0)
+	float4 *cache;                 // cached primary hit per local pixel  (image 1)
+	const uint8_t *shift;          // 2 bytes per local pixel             (image 2)
+	DeviceStats *stats;
+};
+
+__device__ __forceinline__ bool local_pixel_xy(const FrameArgs &f, const int32_t *local_blocks, int L, int *x, int *y)
+{
+	const int blk = local_blocks[L >> 10];
+	const int in = L & 1023, wt = in >> 6, ln = in & 63;
+	const int bx = blk % f.blocks_x, by = blk / f.blocks_x;
+	*x = bx * kBlockDim + (wt & 3) * 8 + (ln & 7);
+	*y = by * kBlockDim + (wt >> 2) * 8 + (ln >> 3);
+	return *x < f.width && *y < f.height;
+}
+
+__device__ __forceinline__ F3 camera_dir(const FrameArgs &f, int px, int py, float bx, float by)
+{
+	float sx = (2.0f * ((float)px + bx)) / (float)f.width - 1.0f;
+	float sy = (2.0f * ((float)py + by)) / (float)f.height - 1.0f;
+	sy = -sy;
+	const float *m = f.inv_proj;
+	F3 t;
+	t.x = fmaf(m[12], 1.0f, fmaf(m[8], 1.0f, fmaf(m[4], sy, m[0] * sx)));
+	t.y = fmaf(m[13], 1.0f, fmaf(m[9], 1.0f, fmaf(m[5], sy, m[1] * sx)));
+	t.z = fmaf(m[14], 1.0f, fmaf(m[10], 1.0f, fmaf(m[6], sy, m[2] * sx)));
+	const float *v = f.inv_view;
+	F3 r;
+	r.x = fmaf(v[8], t.z, fmaf(v[4], t.y, v[0] * t.x));
+	r.y = fmaf(v[9], t.z, fmaf(v[5], t.y, v[1] * t.x));
+	r.z = fmaf(v[10], t.z, fmaf(v[6], t.y, v[2] * t.x));
+	return normalize3(r);
+}
+
+// wave-level stream compaction: returns this lane's output slot (valid only if `alive`)
+__device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t *counter)
+{
+	const unsigned long long mask = __ballot(alive);
+	const uint32_t n = (uint32_t)__popcll(mask);
+	const int lane = threadIdx.x & 63;
+	uint32_t base = 0;
+	if(n != 0 && lane == (int)__builtin_ctzll(mask)) base = atomicAdd(counter, n);
+	base = __shfl(base, n != 0 ? (int)__builtin_ctzll(mask) : 0);
+	return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// use_cache: the frame reuses the cached primary hit (spp % tmpLife != 0, pathtracer.glsl:115-120) — the hit
+// record is copied next to the ray and the host skips the bounce-0 traversal launch.
+// bias_mode 0: Camera() of primaryray.glsl (no sub-pixel bias); 1: Camera(SubPixel()) of pathtracer.glsl
+__global__ __launch_bounds__(256) void k_gen_primary(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int use_cache, int bias_mode)
+{
+	const int L = blockIdx.x * blockDim.x + threadIdx.x;
+	int x = 0, y = 0;
+	const bool alive = L < f.n_local_px && local_pixel_xy(f, sc.local_blocks, L, &x, &y);
+	float bx = 0.0f, by = 0.0f;
+	if(bias_mode)
+	{
+		const int sub_idx = (f.spp / f.tmp_life) % (f.subpixel * f.subpixel);
+		const float unit = 1.0f / (float)f.subpixel;
+		bx = (float)(sub_idx / f.subpixel) * unit;
+		by = (float)(sub_idx % f.subpixel) * unit;
+	}
+	const uint32_t slot = compact_slot(alive, q.count_out);
+	if(!alive) return;
+	const F3 d = camera_dir(f, x, y, bx, by);
+	q.out_o[slot] = make_float4(f.origin[0], f.origin[1], f.origin[2], f.tmin);
+	q.out_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(L));
+	q.out_col[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+	q.out_rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if(use_cache) q.hit[slot] = px.cache[L];
+}
+
+__device__ __forceinline__ int pos_mod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
+
+// GL_LINEAR / GL_REPEAT / RGB8, single level, canonical fp32 weights (see oracle.cpp sample_texture)
+__device__ inline F3 sample_texture(const SceneArgs &sc, int tex, float s, float t)
+{
+	const int4 d = sc.tex_desc[tex];
+	const int w = d.y, h = d.z;
+	const uint32_t *tx = sc.texels + d.x;
+	const float uu = fmaf(s, (float)w, -0.5f), vv = fmaf(t, (float)h, -0.5f);
+	float fu = floorf(uu), fv = floorf(vv);
+	const float a = uu - fu, b = vv - fv;
+	fu = gl_min(gl_max(fu, -1e9f), 1e9f); fv = gl_min(gl_max(fv, -1e9f), 1e9f);
+	const int i0 = pos_mod((int)fu, w), j0 = pos_mod((int)fv, h);
+	const int i1 = i0 + 1 == w ? 0 : i0 + 1, j1 = j0 + 1 == h ? 0 : j0 + 1;
+	auto texel = [&](int i, int j) {
+		const uint32_t p = tx[(size_t)j * w + i];
+		return f3((float)(p & 0xffu) / 255.0f, (float)((p >> 8) & 0xffu) / 255.0f, (float)((p >> 16) & 0xffu) / 255.0f);
+	};
+	const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+	F3 r = texel(i0, j0) * w00;
+	r = fma3(texel(i1, j0), w10, r);
+	r = fma3(texel(i0, j1), w01, r);
+	r = fma3(texel(i1, j1), w11, r);
+	return r;
+}
+
+__device__ __forceinline__ F3 bary3(const float *a, const float *b, const float *c, float u, float v, float w)
+{
+	F3 r = f3(a[0], a[1], a[2]) * u;
+	r = fma3(f3(b[0], b[1], b[2]), v, r);
+	r = fma3(f3(c[0], c[1], c[2]), w, r);
+	return r;
+}
+
+struct Rng { float sx, sy; const float *sobol; };
+__device__ __forceinline__ void sobol2(const Rng &r, int i, float *x, float *y)
+{
+	const float a = r.sobol[2 * i] + r.sx, b = r.sobol[2 * i + 1] + r.sy;
+	*x = a - floorf(a); *y = b - floorf(b);
+}
+__device__ inline F3 sample_hemisphere(const Rng &rng, int b, float e)
+{
+	float rx, ry; sobol2(rng, b, &rx, &ry);
+	rx *= 6.28318530718f;
+	float sin_phi, cos_phi; canon_sincos(rx, &sin_phi, &cos_phi);
+	const float cos_theta = canon_pow(1.0f - ry, 1.0f / (e + 1.0f));
+	const float sin_theta = sqrtf(fmaf(-cos_theta, cos_theta, 1.0f));
+	return normalize3(f3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta));
+}
+__device__ inline F3 align_direction(F3 dir, F3 target)
+{
+	const F3 a = fabsf(target.x) > 0.01f ? f3(0, 1, 0) : f3(1, 0, 0);
+	const F3 u = normalize3(cross3(a, target));
+	const F3 v = cross3(target, u);
+	F3 r = u * dir.x;
+	r = fma3(v, dir.y, r);
+	r = fma3(target, dir.z, r);
+	return r;
+}
+
+// main() accumulate of pathtracer.glsl:224-226, executed once per pixel and frame when its path ends
+__device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs &px, int L, F3 ret)
+{
+	const F3 r = f3(gl_min(ret.x, f.clamp), gl_min(ret.y, f.clamp), gl_min(ret.z, f.clamp));
+	const float4 old = px.accum[L];
+	const float fs = (float)f.spp, fs1 = (float)(f.spp + 1);
+	px.accum[L] = make_float4(fmaf(old.x, fs, r.x) / fs1, fmaf(old.y, fs, r.y) / fs1, fmaf(old.z, fs, r.z) / fs1, 1.0f);
+}
+
+// One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for every live path.
+// store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
+__global__ __launch_bounds__(256) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int b, int store_cache)
+{
+	const uint32_t n_in = *q.count_in;
+	const uint32_t slot_in = blockIdx.x * blockDim.x + threadIdx.x;
+	bool alive = slot_in < n_in;
+	F3 origin = f3(0, 0, 0), dir = f3(0, 0, 1), color = f3(0, 0, 0), ret = f3(0, 0, 0);
+	int L = 0;
+	bool shaded = false, bad_mat = false;
+	if(alive)
+	{
+		const float4 rd = q.ray_d[slot_in], h = q.hit[slot_in], c4 = q.col[slot_in], r4 = q.rad[slot_in];
+		dir = f3(rd.x, rd.y, rd.z);
+		L = __float_as_int(rd.w);
+		color = f3(c4.x, c4.y, c4.z);
+		ret = f3(r4.x, r4.y, r4.z);
+		const int tri_idx = __float_as_int(h.x);
+		const float tu = h.y, tv = h.z;
+		if(store_cache) px.cache[L] = make_float4(h.x, tu, tv, 0.0f);
+
+		if(tri_idx == -1)
+		{
+			ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret);
+			alive = false;
+		}
+		else
+		{
+			const float *tri = sc.triangles + (size_t)tri_idx * 25;
+			const int matid = __float_as_int(tri[24]);
+			if(matid < 0 || matid >= f.n_mats) { alive = false; bad_mat = true; }
+			else
+			{
+				shaded = true;
+				const float4 *mp = sc.materials + (size_t)matid * 4;
+				const float4 md = mp[0], me = mp[1], ms = mp[2], mx = mp[3];
+				const int dtex = __float_as_int(md.x), illum0 = __float_as_int(mx.x);
+				const float shininess = mx.y, ior = mx.w;
+				const float w = 1.0f - tu - tv;
+				F3 normal = normalize3(bary3(tri + 9, tri + 12, tri + 15, tu, tv, w));
+				origin = bary3(tri + 0, tri + 3, tri + 6, tu, tv, w);
+				F3 diffuse;
+				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex)
+				{
+					const float ts = fmaf(tri[22], w, fmaf(tri[20], tv, tri[18] * tu));
+					const float tt = fmaf(tri[23], w, fmaf(tri[21], tv, tri[19] * tu));
+					diffuse = sample_texture(sc, dtex, ts, tt);
+				}
+				else diffuse = f3(md.y, md.z, md.w);
+				const F3 specular = f3(ms.y, ms.z, ms.w);
+				ret = fma3(color, f3(me.y, me.z, me.w), ret);
+				if(illum0 < 6 && dot3(dir, normal) > 0) normal = -normal;
+
+				const uint8_t *sh = px.shift + (size_t)L * 2;
+				const Rng rng{(float)sh[0] / 255.0f, (float)sh[1] / 255.0f, f.sobol};
+				int illum = illum0;
+				bool done = false;
+				if(illum == 2)
+				{
+					const float e = shininess * 0.01f;
+					if(e > 0.3f)
+					{
+						const F3 r = reflect3(dir, normal), shv = sample_hemisphere(rng, b, e);
+						dir = align_direction(shv, r);
+						if(dot3(dir, normal) < 0.0f) alive = false;
+						else
+						{
+							const float pw = canon_pow(dot3(dir, r), e);
+							color = color * fma3(specular, pw, diffuse);
+						}
+						done = true;
+					}
+					else illum = 1;
+				}
+				if(!done)
+				{
+					if(illum == 1)
+					{
+						dir = align_direction(sample_hemisphere(rng, b, 0.0f), normal);
+						color = color * diffuse;
+					}
+					else if(illum >= 3 && illum <= 5)
+					{
+						color = color * specular;
+						dir = reflect3(dir, normal);
+					}
+					else if(illum == 6 || illum == 7)
+					{
+						float eta = ior;
+						float cosi = dot3(dir, normal);
+						float fresnel, etai, etat;
+						if(cosi > 0) { etai = eta; etat = 1.0f; }
+						else { etai = 1.0f; etat = eta; normal = -normal; cosi = -cosi; }
+						eta = etai / etat;
+						const float sint = (etai / etat) * sqrtf(gl_max(0.0f, fmaf(-cosi, cosi, 1.0f)));
+						if(sint >= 1.0f) fresnel = 1.0f;
+						else
+						{
+							const float cost = sqrtf(gl_max(0.0f, fmaf(-sint, sint, 1.0f)));
+							const float A = etat * cosi, B = etai * cost, C = etai * cosi, D = etat * cost;
+							const float Rs = (A - B) / (A + B);
+							const float Rp = (C - D) / (C + D);
+							fresnel = fmaf(Rs, Rs, Rp * Rp) * 0.5f;
+						}
+						const float cos2 = fmaf(-(eta * eta), fmaf(-cosi, cosi, 1.0f), 1.0f);
+						float sx, sy; sobol2(rng, b, &sx, &sy);
+						if(cos2 > 0 && sx >= fresnel)
+						{
+							const float k = fmaf(eta, cosi, sqrtf(cos2));
+							dir = normalize3(fma3(normal, k, dir * eta));
+						}
+						else dir = reflect3(dir, normal);
+					}
+				}
+				if(b + 1 >= f.max_bounce) alive = false; // last loop iteration
+			}
+		}
+		if(!alive) finish_path(f, px, L, ret);
+	}
+	// statistics: one atomic per wave
+	{
+		const unsigned long long m = __ballot(shaded), mb = __ballot(bad_mat);
+		if((threadIdx.x & 63) == 0)
+		{
+			if(m) atomicAdd(&px.stats->shaded, (unsigned long long)__popcll(m));
+			if(mb) atomicAdd(&px.stats->bad_materials, (unsigned long long)__popcll(mb));
+		}
+	}
+	const uint32_t slot = compact_slot(alive, q.count_out);
+	if(alive)
+	{
+		q.out_o[slot] = make_float4(origin.x, origin.y, origin.z, f.tmin);
+		q.out_d[slot] = make_float4(dir.x, dir.y, dir.z, __int_as_float(L));
+		q.out_col[slot] = make_float4(color.x, color.y, color.z, 0.0f);
+		q.out_rad[slot] = make_float4(ret.x, ret.y, ret.z, 0.0f);
+	}
+}
+
+// primaryray.glsl main (:46-94): colour the primary hit by viewer type; also records the hit in the cache image
+__global__ __launch_bounds__(256) void k_viewer(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int viewer_type)
+{
+	const uint32_t n_in = *q.count_in;
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if(slot >= n_in) return;
+	const float4 rd = q.ray_d[slot], h = q.hit[slot];
+	const int L = __float_as_int(rd.w);
+	const int tri_idx = __float_as_int(h.x);
+	const float u = h.y, v = h.z;
+	px.cache[L] = make_float4(h.x, u, v, 0.0f);
+	F3 color = f3(0, 0, 0);
+	if(tri_idx != -1)
+	{
+		const float *tri = sc.triangles + (size_t)tri_idx * 25;
+		const int matid = __float_as_int(tri[24]);
+		if(matid >= 0 && matid < f.n_mats)
+		{
+			const float4 *mp = sc.materials + (size_t)matid * 4;
+			const float4 md = mp[0], me = mp[1], ms = mp[2];
+			const int dtex = __float_as_int(md.x);
+			const float w = 1.0f - u - v;
+			if(viewer_type == 0)
+			{
+				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex)
+				{
+					const float ts = fmaf(tri[22], w, fmaf(tri[20], v, tri[18] * u));
+					const float tt = fmaf(tri[23], w, fmaf(tri[21], v, tri[19] * u));
+					color = sample_texture(sc, dtex, ts, tt);
+				}
+				else color = f3(md.y, md.z, md.w);
+			}
+			else if(viewer_type == 1) color = f3(ms.y, ms.z, ms.w);
+			else if(viewer_type == 2) color = f3(me.y, me.z, me.w);
+			else if(viewer_type == 4) color = normalize3(bary3(tri + 9, tri + 12, tri + 15, u, v, w));
+			else if(viewer_type == 5) color = bary3(tri + 0, tri + 3, tri + 6, u, v, w);
+		}
+		else atomicAdd(&px.stats->bad_materials, 1ull);
+	}
+	px.accum[L] = make_float4(color.x, color.y, color.z, 1.0f);
+}
+
+// compact block-major RGBA (one rank's buffer) -> rows of the W x H x 3 image (row 0 = top)
+__global__ void k_untile(const float4 *local, const int32_t *local_blocks, int n_local_px, int blocks_x, int width, int height, float *rgb)
+{
+	const int L = blockIdx.x * blockDim.x + threadIdx.x;
+	if(L >= n_local_px) return;
+	const int blk = local_blocks[L >> 10];
+	const int in = L & 1023, wt = in >> 6, ln = in & 63;
+	const int x = (blk % blocks_x) * kBlockDim + (wt & 3) * 8 + (ln & 7);
+	const int y = (blk / blocks_x) * kBlockDim + (wt >> 2) * 8 + (ln >> 3);
+	if(x >= width || y >= height) return;
+	const float4 v = local[L];
+	float *o = rgb + ((size_t)y * width + x) * 3;
+	o[0] = v.x; o[1] = v.y; o[2] = v.z;
+}
+
+}  // namespace adypt

@@ -1,0 +1,696 @@
+// C-ABI implementation of include/adypt_hip.h: context, HBM residency of the scene, launch sequencing of the
+// wavefront path tracer on one HIP stream.  Replaces OglScene + OglPathTracer (src/Tracer/*.cpp) of the reference.
+//
+// Per frame (= one OglPathTracer::Trace(true), OglPathTracer.cpp:34-61):
+//     memset counters -> k_gen_primary -> [ k_trace -> k_shade ] x maxBounce      (all on ctx->stream, no host sync;
+//     queue sizes live in device memory, the traversal kernel is persistent, the shade grid covers the worst case)
+// There is no CPU fallback anywhere in this file: without a HIP device adypt_create fails with ADYPT_E_NO_DEVICE.
+#include "kernels.hpp"
+#include "../../../include/adypt_hip.h"
+#include "../../../include/adypt_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace adypt;
+
+namespace {
+
+constexpr int kMaxBounce = 32;
+
+struct FrameCounters {                 // one memset per frame
+	uint32_t count[kMaxBounce + 1];
+	uint32_t cursor[kMaxBounce + 1][kNumSegments];
+};
+
+thread_local std::string g_create_error;
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct adypt_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string error;
+
+	// scene (immutable after create)
+	void *d_nodes = nullptr, *d_woop = nullptr, *d_tri_indices = nullptr, *d_triangles = nullptr, *d_materials = nullptr;
+	void *d_texels = nullptr, *d_tex_desc = nullptr, *d_local_blocks = nullptr;
+	int64_t n_nodes = 0, n_refs = 0, n_tris = 0, n_mats = 0;
+	int n_tex = 0;
+	int width = 0, height = 0, blocks_x = 0, blocks_y = 0, rank = 0, nranks = 1;
+	int n_local_blocks = 0, n_local_px = 0;
+	std::vector<int32_t> local_blocks;
+
+	// per local pixel
+	float4 *d_accum = nullptr, *d_cache = nullptr;
+	uint8_t *d_shift = nullptr;
+
+	// wavefront queues
+	int64_t capacity = 0;
+	float4 *q_o[2] = {nullptr, nullptr}, *q_d[2] = {nullptr, nullptr}, *q_col[2] = {nullptr, nullptr}, *q_rad[2] = {nullptr, nullptr};
+	float4 *d_hit = nullptr;
+	RayStats *d_ray_stats = nullptr;
+	FrameCounters *d_counters = nullptr;
+	DeviceStats *d_stats = nullptr;
+	uint2 *d_spill = nullptr;
+	size_t spill_bytes = 0;
+
+	// launch geometry of the persistent traversal kernel
+	int num_cus = 0, trace_blocks = 0, lds_depth = 0;
+
+	// state
+	adypt_pt_params params{}, pending{};
+	bool have_params = false, have_camera = false, pt_started = false;
+	float origin[3] = {0, 0, 0}, inv_proj[16] = {0}, inv_view[16] = {0};
+	int spp = 0;
+	uint32_t shift_seed_loaded = 0;
+	bool shift_loaded = false;
+	int instrumentation = 0;
+
+	std::vector<EventPair> events;
+	std::vector<EventPair> free_events;
+	double trace_ms = 0, shade_ms = 0;
+	uint32_t trace_launches = 0;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                             \
+	do {                                                                                               \
+		hipError_t e_ = (expr);                                                                        \
+		if(e_ != hipSuccess) {                                                                         \
+			(ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+			return e_ == hipErrorOutOfMemory ? ADYPT_E_OOM : ADYPT_E_HIP;                              \
+		}                                                                                              \
+	} while(0)
+
+int fail(adypt_ctx *c, int code, const std::string &msg) { c->error = msg; return code; }
+
+// block ownership of the pixel-tile shard: diagonal interleave so that every rank gets sky and floor alike
+inline int block_owner(int bx, int by, int nranks) { return (bx + by) % nranks; }
+
+std::vector<int32_t> owned_blocks(int width, int height, int rank, int nranks)
+{
+	const int nbx = (width + kBlockDim - 1) / kBlockDim, nby = (height + kBlockDim - 1) / kBlockDim;
+	std::vector<int32_t> v;
+	for(int by = 0; by < nby; ++by)
+		for(int bx = 0; bx < nbx; ++bx)
+			if(block_owner(bx, by, nranks) == rank) v.push_back(by * nbx + bx);
+	return v;
+}
+
+template <class T> int upload(adypt_ctx *c, void **dst, const T *src, size_t n)
+{
+	size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+	HIP_TRY(c, hipMalloc(dst, bytes));
+	if(n) HIP_TRY(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+	return ADYPT_OK;
+}
+
+// Structural validation of the BVH arrays: a corrupt child/triangle range would make the kernel read out of
+// bounds, which on this hardware can reset the GPU.  Mirrors exactly the address arithmetic of k_trace.
+bool validate_bvh(const adypt_scene_desc &d, std::string *why)
+{
+	if(d.n_nodes <= 0) { *why = "empty node array"; return false; }
+	const uint8_t *nodes = (const uint8_t *)d.nodes;
+	for(int64_t i = 0; i < d.n_nodes; ++i)
+	{
+		const uint8_t *n = nodes + i * 80;
+		uint32_t child_base, tri_base;
+		memcpy(&child_base, n + 16, 4);
+		memcpy(&tri_base, n + 20, 4);
+		const uint8_t imask = n[15];
+		const uint8_t *meta = n + 24;
+		int n_inner = __builtin_popcount(imask);
+		if(n_inner && (uint64_t)child_base + (uint64_t)n_inner > (uint64_t)d.n_nodes) { *why = "node " + std::to_string(i) + ": child range out of bounds"; return false; }
+		for(int s = 0; s < 8; ++s)
+		{
+			const uint32_t m = meta[s];
+			if(m == 0) continue;
+			const bool inner = (m & (m << 1)) & 0x10;
+			if(inner)
+			{
+				// hit bit (24 + widx) must address a set imask bit
+				const uint32_t widx = (m & 31u) - 24u;
+				if(widx > 7 || !((imask >> widx) & 1u)) { *why = "node " + std::to_string(i) + ": inner child not in imask"; return false; }
+			}
+			else
+			{
+				const uint32_t off = m & 31u, bits = (m >> 5) & 7u;
+				const uint32_t top = bits ? 32u - (uint32_t)__builtin_clz(bits) : 0u;
+				if(off + top > 24u) { *why = "node " + std::to_string(i) + ": leaf bits exceed 24"; return false; }
+				if((uint64_t)tri_base + off + top > (uint64_t)d.n_refs) { *why = "node " + std::to_string(i) + ": triangle range out of bounds"; return false; }
+			}
+		}
+	}
+	for(int64_t i = 0; i < d.n_refs; ++i)
+		if(d.tri_indices[i] < 0 || d.tri_indices[i] >= d.n_tris) { *why = "tri_indices[" + std::to_string(i) + "] out of range"; return false; }
+	return true;
+}
+
+hipEvent_t *begin_timing(adypt_ctx *c, int kind)
+{
+	if(!(c->instrumentation & 1)) return nullptr;
+	EventPair p;
+	if(!c->free_events.empty()) { p = c->free_events.back(); c->free_events.pop_back(); }
+	else { if(hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr; }
+	p.kind = kind;
+	c->events.push_back(p);
+	(void)hipEventRecord(c->events.back().a, c->stream);
+	return &c->events.back().b;
+}
+inline void end_timing(adypt_ctx *c, hipEvent_t *stop) { if(stop) (void)hipEventRecord(*stop, c->stream); }
+
+void harvest_events(adypt_ctx *c)
+{
+	for(EventPair &p : c->events)
+	{
+		float ms = 0.0f;
+		if(hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { if(p.kind == 0) { c->trace_ms += ms; ++c->trace_launches; } else c->shade_ms += ms; }
+		c->free_events.push_back(p);
+	}
+	c->events.clear();
+}
+
+int ensure_spill(adypt_ctx *c, int stack_size)
+{
+	const int extra = stack_size - c->lds_depth;
+	if(extra <= 0) return ADYPT_OK;
+	const size_t need = (size_t)extra * (size_t)c->trace_blocks * kTraceThreads * sizeof(uint2);
+	if(need <= c->spill_bytes) return ADYPT_OK;
+	if(c->d_spill) (void)hipFree(c->d_spill);
+	c->d_spill = nullptr; c->spill_bytes = 0;
+	HIP_TRY(c, hipMalloc((void **)&c->d_spill, need));
+	c->spill_bytes = need;
+	return ADYPT_OK;
+}
+
+// geometry of the persistent traversal launch for a given stack size
+int configure_trace(adypt_ctx *c, int stack_size)
+{
+	c->lds_depth = std::max(1, std::min(stack_size, kLdsStackMax));
+	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
+	int per_cu = 0;
+	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
+	per_cu = std::max(1, std::min(per_cu, 8));
+	c->trace_blocks = c->num_cus * per_cu;
+	return ensure_spill(c, stack_size);
+}
+
+int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *cursor, int stack_size, bool stats, RayStats *ray_stats)
+{
+	TraceArgs a;
+	a.nodes = (const uint4 *)c->d_nodes;
+	a.woop = (const float4 *)c->d_woop;
+	a.tri_indices = (const int32_t *)c->d_tri_indices;
+	a.ray_o = c->q_o[parity]; a.ray_d = c->q_d[parity];
+	a.hit = c->d_hit;
+	a.ray_stats = ray_stats;
+	a.count = count; a.cursor = cursor;
+	a.spill = c->d_spill;
+	a.stats = c->d_stats;
+	a.stack_size = stack_size; a.lds_depth = c->lds_depth;
+	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
+	hipEvent_t *stop = begin_timing(c, 0);
+	if(stats) hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
+	else hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
+	end_timing(c, stop);
+	HIP_TRY(c, hipGetLastError());
+	return ADYPT_OK;
+}
+
+void fill_frame(const adypt_ctx *c, FrameArgs *f)
+{
+	memset(f, 0, sizeof(*f));
+	memcpy(f->inv_proj, c->inv_proj, 64); memcpy(f->inv_view, c->inv_view, 64);
+	memcpy(f->origin, c->origin, 12);
+	f->tmin = c->params.ray_tmin;
+	memcpy(f->sun, c->params.sun, 12);
+	f->clamp = c->params.clamp;
+	f->width = c->width; f->height = c->height;
+	f->spp = c->spp; f->subpixel = c->params.subpixel; f->tmp_life = c->params.tmp_lifetime; f->max_bounce = c->params.max_bounce;
+	f->n_local_px = c->n_local_px; f->blocks_x = c->blocks_x; f->rank = c->rank; f->nranks = c->nranks;
+	f->n_tris = (int32_t)c->n_tris; f->n_mats = (int32_t)c->n_mats; f->n_tex = c->n_tex;
+}
+void fill_scene(const adypt_ctx *c, SceneArgs *s)
+{
+	s->triangles = (const float *)c->d_triangles;
+	s->materials = (const float4 *)c->d_materials;
+	s->texels = (const uint32_t *)c->d_texels;
+	s->tex_desc = (const int4 *)c->d_tex_desc;
+	s->local_blocks = (const int32_t *)c->d_local_blocks;
+}
+void fill_pixels(const adypt_ctx *c, PixelArgs *p)
+{
+	p->accum = c->d_accum; p->cache = c->d_cache; p->shift = c->d_shift; p->stats = c->d_stats;
+}
+QueueArgs queue_args(adypt_ctx *c, int in, const uint32_t *count_in, uint32_t *count_out)
+{
+	QueueArgs q;
+	q.ray_o = c->q_o[in]; q.ray_d = c->q_d[in]; q.col = c->q_col[in]; q.rad = c->q_rad[in];
+	q.hit = c->d_hit;
+	q.out_o = c->q_o[in ^ 1]; q.out_d = c->q_d[in ^ 1]; q.out_col = c->q_col[in ^ 1]; q.out_rad = c->q_rad[in ^ 1];
+	q.count_in = count_in; q.count_out = count_out;
+	return q;
+}
+
+int check_async_errors(adypt_ctx *c)
+{
+	DeviceStats st;
+	HIP_TRY(c, hipMemcpy(&st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+	if(st.overflows) return fail(c, ADYPT_E_STACK_OVERFLOW, "traversal stack overflow: increase pathTracer.stackSize (currently " + std::to_string(c->params.stack_size) + ")");
+	return ADYPT_OK;
+}
+
+int load_shift(adypt_ctx *c)
+{
+	if(c->shift_loaded && c->shift_seed_loaded == c->params.shift_seed) return ADYPT_OK;
+	std::vector<uint8_t> full((size_t)c->width * c->height * 2), local((size_t)c->n_local_px * 2, 0);
+	adypt_shift_bytes(c->params.shift_seed, c->width, c->height, full.data());
+	for(int L = 0; L < c->n_local_px; ++L)
+	{
+		const int blk = c->local_blocks[(size_t)(L >> 10)];
+		const int in = L & 1023, wt = in >> 6, ln = in & 63;
+		const int x = (blk % c->blocks_x) * kBlockDim + (wt & 3) * 8 + (ln & 7), y = (blk / c->blocks_x) * kBlockDim + (wt >> 2) * 8 + (ln >> 3);
+		if(x < c->width && y < c->height)
+		{
+			local[(size_t)L * 2] = full[((size_t)y * c->width + x) * 2];
+			local[(size_t)L * 2 + 1] = full[((size_t)y * c->width + x) * 2 + 1];
+		}
+	}
+	HIP_TRY(c, hipMemcpy(c->d_shift, local.data(), local.size(), hipMemcpyHostToDevice));
+	c->shift_loaded = true; c->shift_seed_loaded = c->params.shift_seed;
+	return ADYPT_OK;
+}
+
+int ensure_ray_stats(adypt_ctx *c)
+{
+	if(c->d_ray_stats) return ADYPT_OK;
+	HIP_TRY(c, hipMalloc((void **)&c->d_ray_stats, (size_t)c->capacity * sizeof(RayStats)));
+	return ADYPT_OK;
+}
+
+// update_config_args (OglPathTracer.cpp:214-225): pending parameters become active
+int apply_params(adypt_ctx *c)
+{
+	c->params = c->pending;
+	int r = configure_trace(c, c->params.stack_size);
+	if(r != ADYPT_OK) return r;
+	return load_shift(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int adypt_abi_version(void) { return ADYPT_ABI_VERSION; }
+
+const char *adypt_last_error(const adypt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int64_t adypt_shard_block_count(int width, int height, int rank, int nranks)
+{
+	if(width <= 0 || height <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return -1;
+	return (int64_t)owned_blocks(width, height, rank, nranks).size();
+}
+
+int adypt_untile_host(int width, int height, int rank, int nranks, const float *local_rgba, float *rgb)
+{
+	if(width <= 0 || height <= 0 || nranks <= 0 || rank < 0 || rank >= nranks || !local_rgba || !rgb) return ADYPT_E_INVALID;
+	const std::vector<int32_t> blocks = owned_blocks(width, height, rank, nranks);
+	const int nbx = (width + kBlockDim - 1) / kBlockDim;
+	for(size_t bi = 0; bi < blocks.size(); ++bi)
+		for(int in = 0; in < kBlockPixels; ++in)
+		{
+			const int wt = in >> 6, ln = in & 63;
+			const int x = (blocks[bi] % nbx) * kBlockDim + (wt & 3) * 8 + (ln & 7), y = (blocks[bi] / nbx) * kBlockDim + (wt >> 2) * 8 + (ln >> 3);
+			if(x >= width || y >= height) continue;
+			const float *s = local_rgba + (bi * kBlockPixels + (size_t)in) * 4;
+			float *o = rgb + ((size_t)y * width + x) * 3;
+			o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+		}
+	return ADYPT_OK;
+}
+
+int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
+{
+	g_create_error.clear();
+	if(!out || !d) { g_create_error = "adypt_create: null argument"; return ADYPT_E_INVALID; }
+	*out = nullptr;
+	if(!d->nodes || !d->tri_indices || !d->triangles || d->n_nodes <= 0 || d->n_refs < 0 || d->n_tris <= 0 || d->n_mats < 0 ||
+	   d->width <= 0 || d->height <= 0 || d->n_textures < 0 || (d->n_mats > 0 && !d->materials) || (d->n_textures > 0 && !d->textures) ||
+	   d->tile_nranks <= 0 || d->tile_rank < 0 || d->tile_rank >= d->tile_nranks)
+	{ g_create_error = "adypt_create: inconsistent scene description"; return ADYPT_E_INVALID; }
+	if((int64_t)d->width * d->height > (int64_t)1 << 30) { g_create_error = "adypt_create: image too large"; return ADYPT_E_INVALID; }
+	{
+		std::string why;
+		if(!validate_bvh(*d, &why)) { g_create_error = "adypt_create: invalid BVH arrays: " + why; return ADYPT_E_INVALID; }
+	}
+	int n_dev = 0;
+	if(hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { g_create_error = "adypt_create: no HIP device available (this library has no CPU path)"; return ADYPT_E_NO_DEVICE; }
+	if(d->device < 0 || d->device >= n_dev) { g_create_error = "adypt_create: device ordinal out of range"; return ADYPT_E_INVALID; }
+
+	adypt_ctx *c = new adypt_ctx();
+	auto bail = [&](int code) { g_create_error = c->error; adypt_destroy(c); return code; };
+	c->device = d->device;
+	int r;
+#define TRY_CREATE(expr) do { r = (expr); if(r != ADYPT_OK) return bail(r); } while(0)
+#define HIP_CREATE(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) { c->error = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? ADYPT_E_OOM : ADYPT_E_HIP); } } while(0)
+	HIP_CREATE(hipSetDevice(c->device));
+	HIP_CREATE(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	hipDeviceProp_t prop;
+	HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
+	c->num_cus = prop.multiProcessorCount;
+
+	c->n_nodes = d->n_nodes; c->n_refs = d->n_refs; c->n_tris = d->n_tris; c->n_mats = d->n_mats; c->n_tex = d->n_textures;
+	c->width = d->width; c->height = d->height; c->rank = d->tile_rank; c->nranks = d->tile_nranks;
+	c->blocks_x = (c->width + kBlockDim - 1) / kBlockDim; c->blocks_y = (c->height + kBlockDim - 1) / kBlockDim;
+	c->local_blocks = owned_blocks(c->width, c->height, c->rank, c->nranks);
+	c->n_local_blocks = (int)c->local_blocks.size();
+	c->n_local_px = c->n_local_blocks * kBlockPixels;
+
+	TRY_CREATE(upload(c, &c->d_nodes, (const uint8_t *)d->nodes, (size_t)d->n_nodes * 80));
+	TRY_CREATE(upload(c, &c->d_tri_indices, d->tri_indices, (size_t)d->n_refs));
+	{
+		std::vector<float> woop;
+		const float *wp = d->woop;
+		if(!wp) { woop.resize((size_t)d->n_refs * 12); adypt_woop_matrices(d->triangles, d->tri_indices, d->n_refs, woop.data()); wp = woop.data(); }
+		TRY_CREATE(upload(c, &c->d_woop, wp, (size_t)d->n_refs * 12));
+	}
+	TRY_CREATE(upload(c, &c->d_triangles, (const uint8_t *)d->triangles, (size_t)d->n_tris * 100));
+	TRY_CREATE(upload(c, &c->d_materials, (const uint8_t *)d->materials, (size_t)d->n_mats * 64));
+	{
+		std::vector<uint32_t> texels;
+		std::vector<int32_t> desc;
+		for(int t = 0; t < d->n_textures; ++t)
+		{
+			const adypt_texture &tx = d->textures[t];
+			if(tx.width <= 0 || tx.height <= 0 || !tx.rgb) { c->error = "adypt_create: bad texture " + std::to_string(t); return bail(ADYPT_E_INVALID); }
+			desc.push_back((int32_t)texels.size()); desc.push_back(tx.width); desc.push_back(tx.height); desc.push_back(0);
+			const size_t n = (size_t)tx.width * tx.height;
+			const size_t base = texels.size();
+			texels.resize(base + n);
+			for(size_t i = 0; i < n; ++i) texels[base + i] = (uint32_t)tx.rgb[i * 3] | (uint32_t)tx.rgb[i * 3 + 1] << 8 | (uint32_t)tx.rgb[i * 3 + 2] << 16 | 0xff000000u;
+		}
+		TRY_CREATE(upload(c, &c->d_texels, texels.data(), texels.size()));
+		TRY_CREATE(upload(c, &c->d_tex_desc, desc.data(), desc.size()));
+	}
+	TRY_CREATE(upload(c, &c->d_local_blocks, c->local_blocks.data(), c->local_blocks.size()));
+
+	const size_t npx = (size_t)std::max(c->n_local_px, 64);
+	HIP_CREATE(hipMalloc((void **)&c->d_accum, npx * sizeof(float4)));
+	HIP_CREATE(hipMalloc((void **)&c->d_cache, npx * sizeof(float4)));
+	HIP_CREATE(hipMalloc((void **)&c->d_shift, npx * 2));
+	HIP_CREATE(hipMemset(c->d_accum, 0, npx * sizeof(float4)));
+	HIP_CREATE(hipMemset(c->d_cache, 0xff, npx * sizeof(float4)));
+	HIP_CREATE(hipMemset(c->d_shift, 0, npx * 2));
+	c->capacity = (int64_t)npx;
+	for(int i = 0; i < 2; ++i)
+	{
+		HIP_CREATE(hipMalloc((void **)&c->q_o[i], npx * sizeof(float4)));
+		HIP_CREATE(hipMalloc((void **)&c->q_d[i], npx * sizeof(float4)));
+		HIP_CREATE(hipMalloc((void **)&c->q_col[i], npx * sizeof(float4)));
+		HIP_CREATE(hipMalloc((void **)&c->q_rad[i], npx * sizeof(float4)));
+	}
+	HIP_CREATE(hipMalloc((void **)&c->d_hit, npx * sizeof(float4)));
+	HIP_CREATE(hipMalloc((void **)&c->d_counters, sizeof(FrameCounters)));
+	HIP_CREATE(hipMalloc((void **)&c->d_stats, sizeof(DeviceStats)));
+	HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(FrameCounters)));
+	HIP_CREATE(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
+
+	// defaults of InstanceConfig::PT (src/InstanceConfig.hpp:21-27), seed 0
+	c->pending.stack_size = 12; c->pending.max_bounce = 5; c->pending.subpixel = 8; c->pending.tmp_lifetime = 16;
+	c->pending.ray_tmin = 0.0001f; c->pending.clamp = 4.0f; c->pending.sun[0] = c->pending.sun[1] = c->pending.sun[2] = 0.0f;
+	c->pending.shift_seed = 0;
+	TRY_CREATE(apply_params(c));
+	HIP_CREATE(hipStreamSynchronize(c->stream));
+#undef TRY_CREATE
+#undef HIP_CREATE
+	*out = c;
+	return ADYPT_OK;
+}
+
+void adypt_destroy(adypt_ctx *c)
+{
+	if(!c) return;
+	(void)hipSetDevice(c->device);
+	if(c->stream) (void)hipStreamSynchronize(c->stream);
+	for(EventPair &p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+	void *bufs[] = {c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
+					c->d_accum, c->d_cache, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->q_rad[0], c->q_rad[1],
+					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill};
+	for(void *b : bufs) if(b) (void)hipFree(b);
+	if(c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int adypt_set_params(adypt_ctx *c, const adypt_pt_params *p)
+{
+	if(!c || !p) return ADYPT_E_INVALID;
+	if(p->stack_size < 1 || p->stack_size > 64 || p->max_bounce < 1 || p->max_bounce > kMaxBounce || p->subpixel < 1 || p->tmp_lifetime < 1)
+		return fail(c, ADYPT_E_INVALID, "adypt_set_params: stackSize must be in [1,64], maxBounce in [1,32], subpixel and tmpLifetime >= 1");
+	c->pending = *p;
+	c->have_params = true;
+	if(!c->pt_started)
+	{
+		HIP_TRY(c, hipSetDevice(c->device));
+		return apply_params(c);
+	}
+	return ADYPT_OK;
+}
+
+int adypt_set_camera(adypt_ctx *c, const float origin[3], const float inv_proj[16], const float inv_view[16])
+{
+	if(!c || !origin || !inv_proj || !inv_view) return ADYPT_E_INVALID;
+	memcpy(c->origin, origin, 12); memcpy(c->inv_proj, inv_proj, 64); memcpy(c->inv_view, inv_view, 64);
+	c->have_camera = true;
+	return ADYPT_OK;
+}
+
+int adypt_reset(adypt_ctx *c)
+{
+	if(!c) return ADYPT_E_INVALID;
+	c->pt_started = false;
+	c->spp = 0;
+	return ADYPT_OK;
+}
+
+int adypt_get_spp(const adypt_ctx *c) { return c ? c->spp : ADYPT_E_INVALID; }
+
+int adypt_set_instrumentation(adypt_ctx *c, int flags)
+{
+	if(!c) return ADYPT_E_INVALID;
+	c->instrumentation = flags;
+	return ADYPT_OK;
+}
+
+int adypt_trace_primary(adypt_ctx *c, int viewer_type)
+{
+	if(!c) return ADYPT_E_INVALID;
+	if(!c->have_camera) return fail(c, ADYPT_E_STATE, "adypt_trace_primary: call adypt_set_camera first");
+	HIP_TRY(c, hipSetDevice(c->device));
+	// Trace(false): leaves path-tracing mode (OglPathTracer.cpp:53-58)
+	c->pt_started = false; c->spp = 0;
+	int r = apply_params(c);
+	if(r != ADYPT_OK) return r;
+	FrameArgs f; SceneArgs sc; PixelArgs px;
+	fill_frame(c, &f); fill_scene(c, &sc); fill_pixels(c, &px);
+	HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
+	const int grid = (c->n_local_px + 255) / 256;
+	{
+		QueueArgs q = queue_args(c, 1, &c->d_counters->count[0], &c->d_counters->count[0]); // writes queue 0
+		hipEvent_t *stop = begin_timing(c, 1);
+		hipLaunchKernelGGL(k_gen_primary, dim3(grid), dim3(256), 0, c->stream, f, sc, q, px, 0, 0);
+		end_timing(c, stop);
+	}
+	r = launch_trace(c, 0, &c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr);
+	if(r != ADYPT_OK) return r;
+	{
+		QueueArgs q = queue_args(c, 0, &c->d_counters->count[0], &c->d_counters->count[1]);
+		hipEvent_t *stop = begin_timing(c, 1);
+		hipLaunchKernelGGL(k_viewer, dim3(grid), dim3(256), 0, c->stream, f, sc, q, px, viewer_type);
+		end_timing(c, stop);
+	}
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	harvest_events(c);
+	return check_async_errors(c);
+}
+
+int adypt_trace_spp(adypt_ctx *c, int n_spp)
+{
+	if(!c || n_spp < 0) return ADYPT_E_INVALID;
+	if(!c->have_camera) return fail(c, ADYPT_E_STATE, "adypt_trace_spp: call adypt_set_camera first");
+	HIP_TRY(c, hipSetDevice(c->device));
+	SceneArgs sc; PixelArgs px;
+	fill_scene(c, &sc); fill_pixels(c, &px);
+	const int grid = (c->n_local_px + 255) / 256;
+	const bool stats = (c->instrumentation & 2) != 0;
+	for(int s = 0; s < n_spp; ++s)
+	{
+		if(!c->pt_started)
+		{
+			// first path-traced frame (OglPathTracer.cpp:39-46): apply config, clear the result image, restart Sobol
+			int r = apply_params(c);
+			if(r != ADYPT_OK) return r;
+			HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)std::max(c->n_local_px, 64) * sizeof(float4), c->stream));
+			c->spp = 0;
+			c->pt_started = true;
+		}
+		const int max_bounce = c->params.max_bounce;
+		FrameArgs f;
+		fill_frame(c, &f);
+		{
+			// Sobol::Next (src/Util/Sobol.cpp:16-21): gray-code update with the lowest zero bit of the frame index
+			float pt[64];
+			int r = adypt_sobol_points(2 * max_bounce, c->spp, 1, pt);
+			if(r != ADYPT_OK) return fail(c, r, adypt_host_last_error());
+			memcpy(f.sobol, pt, sizeof(float) * 2 * (size_t)max_bounce);
+		}
+		const int use_cache = (c->spp % c->params.tmp_lifetime) != 0;
+		HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
+		{
+			QueueArgs q = queue_args(c, 1, &c->d_counters->count[0], &c->d_counters->count[0]); // out = queue 0
+			hipEvent_t *stop = begin_timing(c, 1);
+			hipLaunchKernelGGL(k_gen_primary, dim3(grid), dim3(256), 0, c->stream, f, sc, q, px, use_cache, 1);
+			end_timing(c, stop);
+		}
+		for(int b = 0; b < max_bounce; ++b)
+		{
+			const int in = b & 1;
+			if(!(b == 0 && use_cache))
+			{
+				int r = launch_trace(c, in, &c->d_counters->count[b], c->d_counters->cursor[b], c->params.stack_size, stats, nullptr);
+				if(r != ADYPT_OK) return r;
+			}
+			QueueArgs q = queue_args(c, in, &c->d_counters->count[b], &c->d_counters->count[b + 1]);
+			hipEvent_t *stop = begin_timing(c, 1);
+			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, c->stream, f, sc, q, px, b, (b == 0 && !use_cache) ? 1 : 0);
+			end_timing(c, stop);
+		}
+		HIP_TRY(c, hipGetLastError());
+		++c->spp;
+	}
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	harvest_events(c);
+	return check_async_errors(c);
+}
+
+int adypt_read_radiance(adypt_ctx *c, float *rgb)
+{
+	if(!c || !rgb) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	std::vector<float> local((size_t)c->n_local_px * 4);
+	HIP_TRY(c, hipMemcpy(local.data(), c->d_accum, local.size() * sizeof(float), hipMemcpyDeviceToHost));
+	return adypt_untile_host(c->width, c->height, c->rank, c->nranks, local.data(), rgb);
+}
+
+int adypt_read_hits(adypt_ctx *c, int32_t *tri, float *uv)
+{
+	if(!c || !tri || !uv) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	std::vector<float> local((size_t)c->n_local_px * 4);
+	HIP_TRY(c, hipMemcpy(local.data(), c->d_cache, local.size() * sizeof(float), hipMemcpyDeviceToHost));
+	for(int L = 0; L < c->n_local_px; ++L)
+	{
+		const int blk = c->local_blocks[(size_t)(L >> 10)];
+		const int in = L & 1023, wt = in >> 6, ln = in & 63;
+		const int x = (blk % c->blocks_x) * kBlockDim + (wt & 3) * 8 + (ln & 7), y = (blk / c->blocks_x) * kBlockDim + (wt >> 2) * 8 + (ln >> 3);
+		if(x >= c->width || y >= c->height) continue;
+		const size_t p = (size_t)y * c->width + x;
+		memcpy(&tri[p], &local[(size_t)L * 4], 4);
+		uv[p * 2] = local[(size_t)L * 4 + 1]; uv[p * 2 + 1] = local[(size_t)L * 4 + 2];
+	}
+	return ADYPT_OK;
+}
+
+int adypt_trace_rays(adypt_ctx *c, const float *rays, int64_t n, adypt_hit *hits, int with_stats)
+{
+	if(!c || n < 0 || (n > 0 && (!rays || !hits))) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	if(!c->pt_started) { int r = apply_params(c); if(r != ADYPT_OK) return r; }
+	if(with_stats) { int r = ensure_ray_stats(c); if(r != ADYPT_OK) return r; }
+	std::vector<float4> o, d, h;
+	std::vector<RayStats> rs;
+	for(int64_t done = 0; done < n;)
+	{
+		const int64_t m = std::min<int64_t>(n - done, c->capacity);
+		o.resize((size_t)m); d.resize((size_t)m); h.resize((size_t)m);
+		for(int64_t i = 0; i < m; ++i)
+		{
+			const float *r = rays + (size_t)(done + i) * 8;
+			o[(size_t)i] = make_float4(r[0], r[1], r[2], r[3]);
+			d[(size_t)i] = make_float4(r[4], r[5], r[6], 0.0f);
+		}
+		HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->q_o[0], o.data(), (size_t)m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->q_d[0], d.data(), (size_t)m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+		const uint32_t cnt = (uint32_t)m;
+		HIP_TRY(c, hipMemcpyAsync(&c->d_counters->count[0], &cnt, 4, hipMemcpyHostToDevice, c->stream));
+		int r = launch_trace(c, 0, &c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, with_stats != 0, with_stats ? c->d_ray_stats : nullptr);
+		if(r != ADYPT_OK) return r;
+		HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_hit, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+		if(with_stats)
+		{
+			rs.resize((size_t)m);
+			HIP_TRY(c, hipMemcpyAsync(rs.data(), c->d_ray_stats, (size_t)m * sizeof(RayStats), hipMemcpyDeviceToHost, c->stream));
+		}
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		for(int64_t i = 0; i < m; ++i)
+		{
+			adypt_hit &out = hits[done + i];
+			memcpy(&out.tri_id, &h[(size_t)i].x, 4);
+			out.u = h[(size_t)i].y; out.v = h[(size_t)i].z; out.t = h[(size_t)i].w;
+			if(with_stats)
+			{
+				const RayStats &s = rs[(size_t)i];
+				out.ref_idx = s.ref_idx; out.nodes = s.nodes; out.tris = s.tris; out.hash = s.hash; out.max_depth = s.max_depth;
+			}
+			else { out.ref_idx = out.tri_id == -1 ? -1 : 0; out.nodes = out.tris = out.hash = out.max_depth = 0; }
+		}
+		done += m;
+	}
+	harvest_events(c);
+	return ADYPT_OK; // stack overflows of arbitrary batches are reported per ray (max_depth = 0xffffffff) and in the stats
+}
+
+int adypt_get_stats(adypt_ctx *c, adypt_stats *out)
+{
+	if(!c || !out) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	harvest_events(c);
+	DeviceStats st;
+	HIP_TRY(c, hipMemcpy(&st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+	out->rays = st.rays; out->nodes_visited = st.nodes; out->tris_tested = st.tris; out->hits = st.hits; out->shaded = st.shaded;
+	out->stack_overflows = st.overflows; out->bad_materials = st.bad_materials; out->max_stack = st.max_stack;
+	out->trace_launches = c->trace_launches; out->trace_ms = c->trace_ms; out->shade_ms = c->shade_ms;
+	return ADYPT_OK;
+}
+
+int adypt_reset_stats(adypt_ctx *c)
+{
+	if(!c) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	harvest_events(c);
+	HIP_TRY(c, hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
+	c->trace_ms = c->shade_ms = 0; c->trace_launches = 0;
+	return ADYPT_OK;
+}
+
+int64_t adypt_local_pixel_count(const adypt_ctx *c) { return c ? c->n_local_px : ADYPT_E_INVALID; }
+
+int adypt_local_radiance_device(adypt_ctx *c, void **dptr)
+{
+	if(!c || !dptr) return ADYPT_E_INVALID;
+	*dptr = c->d_accum;
+	return ADYPT_OK;
+}
+
+}  // extern "C"
