@@ -368,6 +368,9 @@ class HipPathTracer:
         N.check(N.lib.adypt_local_radiance_device(self._ctx, C.byref(p)), self._ctx)
         return p.value
 
+    def copy_local_radiance(self, dst_device_ptr: int, capacity_float4: int) -> None:
+        N.check(N.lib.adypt_copy_local_radiance(self._ctx, dst_device_ptr, capacity_float4), self._ctx)
+
     def destroy(self) -> None:
         if self._ctx:
             N.lib.adypt_destroy(self._ctx)

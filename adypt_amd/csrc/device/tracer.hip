@@ -686,6 +686,17 @@ int adypt_reset_stats(adypt_ctx *c)
 
 int64_t adypt_local_pixel_count(const adypt_ctx *c) { return c ? c->n_local_px : ADYPT_E_INVALID; }
 
+int adypt_copy_local_radiance(adypt_ctx *c, void *dst, int64_t capacity_float4)
+{
+	if(!c || !dst || capacity_float4 < c->n_local_px) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipMemcpyAsync(dst, c->d_accum, (size_t)c->n_local_px * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+	if(capacity_float4 > c->n_local_px)
+		HIP_TRY(c, hipMemsetAsync((char *)dst + (size_t)c->n_local_px * sizeof(float4), 0, (size_t)(capacity_float4 - c->n_local_px) * sizeof(float4), c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return ADYPT_OK;
+}
+
 int adypt_local_radiance_device(adypt_ctx *c, void **dptr)
 {
 	if(!c || !dptr) return ADYPT_E_INVALID;

@@ -12,7 +12,6 @@
 #include "../../../include/adypt_hip.h"
 #include "../../../include/adypt_host.h"
 
-#include <charconv>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -326,20 +325,142 @@ void write_exponent(std::string *o, int k)
 	*o += std::to_string(k);
 }
 
+// ---- Grisu2 (Loitsch, PLDI 2010) — the double -> shortest-ish decimal conversion behind rapidjson's Writer::Double.
+// Reproduced (not just "shortest round trip") because Grisu2 occasionally emits a different final digit than the
+// closest shortest representation (e.g. float 0.3 -> 0.30000001192092898), and GetJson() text is pinned by golden files.
+struct DiyFp {
+	uint64_t f; int e;
+	DiyFp() : f(0), e(0) {}
+	DiyFp(uint64_t f_, int e_) : f(f_), e(e_) {}
+	explicit DiyFp(double d)
+	{
+		uint64_t u; memcpy(&u, &d, 8);
+		const int biased = (int)((u >> 52) & 0x7ff);
+		const uint64_t sig = u & 0x000fffffffffffffull;
+		if(biased != 0) { f = sig + 0x0010000000000000ull; e = biased - 0x433; }
+		else { f = sig; e = 1 - 0x433; }
+	}
+	DiyFp operator-(const DiyFp &r) const { return DiyFp(f - r.f, e); }
+	DiyFp operator*(const DiyFp &r) const
+	{
+		const unsigned __int128 p = (unsigned __int128)f * r.f;
+		uint64_t h = (uint64_t)(p >> 64);
+		if((uint64_t)p & (1ull << 63)) ++h; // round half up
+		return DiyFp(h, e + r.e + 64);
+	}
+	DiyFp normalize() const { int s = __builtin_clzll(f); return DiyFp(f << s, e - s); }
+	DiyFp normalize_boundary() const
+	{
+		DiyFp r = *this;
+		while(!(r.f & (0x0010000000000000ull << 1))) { r.f <<= 1; r.e--; }
+		r.f <<= (64 - 52 - 2); r.e -= (64 - 52 - 2);
+		return r;
+	}
+	void boundaries(DiyFp *minus, DiyFp *plus) const
+	{
+		DiyFp pl = DiyFp((f << 1) + 1, e - 1).normalize_boundary();
+		DiyFp mi = (f == 0x0010000000000000ull) ? DiyFp((f << 2) - 1, e - 2) : DiyFp((f << 1) - 1, e - 1);
+		mi.f <<= mi.e - pl.e;
+		mi.e = pl.e;
+		*plus = pl; *minus = mi;
+	}
+};
+
+const struct { uint64_t f; int e; } kPow10Cache[87] = {
+#include "grisu_pow10.inc"
+};
+
+DiyFp cached_power(int e, int *K)
+{
+	const double dk = (-61 - e) * 0.30102999566398114 + 347;
+	int k = (int)dk;
+	if(dk - k > 0.0) ++k;
+	const unsigned index = (unsigned)((k >> 3) + 1);
+	*K = -(-348 + (int)(index << 3));
+	return DiyFp(kPow10Cache[index].f, kPow10Cache[index].e);
+}
+
+void grisu_round(char *buf, int len, uint64_t delta, uint64_t rest, uint64_t ten_kappa, uint64_t wp_w)
+{
+	while(rest < wp_w && delta - rest >= ten_kappa && (rest + ten_kappa < wp_w || wp_w - rest > rest + ten_kappa - wp_w))
+	{
+		buf[len - 1]--;
+		rest += ten_kappa;
+	}
+}
+
+int decimal_digits32(uint32_t n)
+{
+	int digits = 1;
+	for(uint32_t lim = 10; digits < 9 && n >= lim; lim *= 10) ++digits;
+	return digits;
+}
+
+void digit_gen(const DiyFp &W, const DiyFp &Mp, uint64_t delta, char *buf, int *len, int *K)
+{
+	static const uint32_t kPow10[] = {1, 10, 100, 1000, 10000, 100000, 1000000, 10000000, 100000000, 1000000000};
+	const DiyFp one((uint64_t)1 << -Mp.e, Mp.e);
+	const DiyFp wp_w = Mp - W;
+	uint32_t p1 = (uint32_t)(Mp.f >> -one.e);
+	uint64_t p2 = Mp.f & (one.f - 1);
+	int kappa = decimal_digits32(p1);
+	*len = 0;
+	while(kappa > 0)
+	{
+		const uint32_t div = kPow10[kappa - 1];
+		const uint32_t d = p1 / div;
+		p1 %= div;
+		if(d || *len) buf[(*len)++] = (char)('0' + d);
+		--kappa;
+		const uint64_t tmp = ((uint64_t)p1 << -one.e) + p2;
+		if(tmp <= delta)
+		{
+			*K += kappa;
+			grisu_round(buf, *len, delta, tmp, (uint64_t)kPow10[kappa] << -one.e, wp_w.f);
+			return;
+		}
+	}
+	for(;;)
+	{
+		p2 *= 10;
+		delta *= 10;
+		const char d = (char)(p2 >> -one.e);
+		if(d || *len) buf[(*len)++] = (char)('0' + d);
+		p2 &= one.f - 1;
+		--kappa;
+		if(p2 < delta)
+		{
+			*K += kappa;
+			const int index = -kappa;
+			grisu_round(buf, *len, delta, p2, one.f, wp_w.f * (index < 9 ? kPow10[index] : 0));
+			return;
+		}
+	}
+}
+
+void grisu2(double value, char *buf, int *len, int *K)
+{
+	const DiyFp v(value);
+	DiyFp w_m, w_p;
+	v.boundaries(&w_m, &w_p);
+	const DiyFp c_mk = cached_power(w_p.e, K);
+	const DiyFp W = v.normalize() * c_mk;
+	DiyFp Wp = w_p * c_mk, Wm = w_m * c_mk;
+	Wm.f++;
+	Wp.f--;
+	digit_gen(W, Wp, Wp.f - Wm.f, buf, len, K);
+}
+
 void write_double(std::string *o, double d)
 {
 	if(d == 0.0) { *o += std::signbit(d) ? "-0.0" : "0.0"; return; }
 	if(d < 0) { o->push_back('-'); d = -d; }
-	char buf[64];
-	auto r = std::to_chars(buf, buf + sizeof(buf), d, std::chars_format::scientific); // shortest round-trip digits
-	std::string sci(buf, r.ptr);
-	size_t epos = sci.find('e');
-	std::string digits;
-	for(size_t i = 0; i < epos; ++i) if(sci[i] != '.') digits.push_back(sci[i]);
-	int exp10 = atoi(sci.c_str() + epos + 1);
-	const int length = (int)digits.size();
-	const int k = exp10 - (length - 1); // value = digits * 10^k
-	const int kk = length + k;          // 10^(kk-1) <= value < 10^kk
+	char buf[32];
+	int length = 0, k = 0; // value = digits * 10^k
+	grisu2(d, buf, &length, &k);
+	const std::string digits(buf, (size_t)length);
+	const int kk = length + k; // 10^(kk-1) <= value < 10^kk
+	// rapidjson Prettify with the default maxDecimalPlaces (324)
 	if(0 <= k && kk <= 21) { *o += digits; o->append((size_t)k, '0'); *o += ".0"; }
 	else if(0 < kk && kk <= 21) { o->append(digits, 0, (size_t)kk); o->push_back('.'); o->append(digits, (size_t)kk, std::string::npos); }
 	else if(-6 < kk && kk <= 0) { *o += "0."; o->append((size_t)(-kk), '0'); *o += digits; }

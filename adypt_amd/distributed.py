@@ -1,0 +1,82 @@
+"""Pixel-tile sharding across GPUs: one process per GPU, zero communication while rendering, ONE gather of the fp32
+radiance per output frame.
+
+The image is cut into 32x32-pixel blocks; block (bx, by) belongs to rank (bx + by) mod world (diagonal interleave:
+sky, floor and geometry-heavy regions are spread evenly).  Every rank renders only its blocks into a compact
+block-major RGBA buffer; pixels are independent (pathtracer.glsl:220-227 has no cross-pixel reduction, the Sobol
+point is per frame, the shift per pixel), so the assembled image is bit-identical to a single-GPU render.
+
+`gather_radiance` works on any torch.distributed backend: "nccl" (= RCCL over xGMI) on GPUs with device tensors,
+"gloo" on CPU (used by the world_size-2 CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import _native as N
+
+BLOCK = 32
+BLOCK_PIXELS = BLOCK * BLOCK
+
+
+def block_count(width: int, height: int, rank: int, world: int) -> int:
+    n = N.lib.adypt_shard_block_count(width, height, rank, world)
+    if n < 0:
+        raise ValueError("bad shard geometry")
+    return int(n)
+
+
+def max_block_count(width: int, height: int, world: int) -> int:
+    return max(block_count(width, height, r, world) for r in range(world))
+
+
+def owner_mask(width: int, height: int, rank: int, world: int) -> np.ndarray:
+    """uint8 H x W mask of the pixels rank `rank` renders."""
+    by, bx = np.mgrid[0:height, 0:width]
+    return (((bx // BLOCK) + (by // BLOCK)) % world == rank).astype(np.uint8)
+
+
+def tile_from_image(rgba: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """H x W x 4 image -> compact block-major float4 buffer of `rank` (inverse of untile; used by CPU tests)."""
+    h, w = rgba.shape[:2]
+    nbx, nby = (w + BLOCK - 1) // BLOCK, (h + BLOCK - 1) // BLOCK
+    out = []
+    for by in range(nby):
+        for bx in range(nbx):
+            if (bx + by) % world != rank:
+                continue
+            blk = np.zeros((BLOCK, BLOCK, 4), dtype=np.float32)
+            src = rgba[by * BLOCK:(by + 1) * BLOCK, bx * BLOCK:(bx + 1) * BLOCK]
+            blk[:src.shape[0], :src.shape[1]] = src
+            # 16 wave tiles of 8x8 (4 per row), each row-major
+            out.append(blk.reshape(4, 8, 4, 8, 4).transpose(0, 2, 1, 3, 4).reshape(BLOCK_PIXELS, 4))
+    return np.concatenate(out, axis=0) if out else np.zeros((0, 4), dtype=np.float32)
+
+
+def untile(width: int, height: int, rank: int, world: int, local_rgba: np.ndarray, rgb: np.ndarray) -> None:
+    local_rgba = np.ascontiguousarray(local_rgba, dtype=np.float32)
+    assert rgb.dtype == np.float32 and rgb.flags.c_contiguous and rgb.shape == (height, width, 3)
+    assert local_rgba.size >= block_count(width, height, rank, world) * BLOCK_PIXELS * 4
+    N.check_host(N.lib.adypt_untile_host(width, height, rank, world, local_rgba.ctypes.data, rgb.ctypes.data))
+
+
+def gather_radiance(local, width: int, height: int, rank: int, world: int, group=None) -> Optional[np.ndarray]:
+    """`local`: 1-D float32 torch tensor (device or CPU) holding this rank's compact buffer padded with zeros to
+    max_block_count * 1024 * 4 floats.  Returns the assembled H x W x 3 image on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    n = max_block_count(width, height, world) * BLOCK_PIXELS * 4
+    assert local.numel() == n and local.dtype == torch.float32
+    if world == 1:
+        parts = [local]
+    else:
+        parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+        dist.gather(local, gather_list=parts, dst=0, group=group)  # the single collective of the data path
+    if rank != 0:
+        return None
+    rgb = np.zeros((height, width, 3), dtype=np.float32)
+    for r in range(world):
+        untile(width, height, r, world, parts[r].detach().cpu().numpy(), rgb)
+    return rgb

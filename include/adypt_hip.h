@@ -140,6 +140,9 @@ int adypt_reset_stats(adypt_ctx *ctx);
 int64_t adypt_local_pixel_count(const adypt_ctx *ctx);
 /* device pointer of the compact local radiance buffer (float4 per local pixel, block-major) */
 int adypt_local_radiance_device(adypt_ctx *ctx, void **dptr);
+/* device-to-device copy of the compact local radiance into caller-owned device memory (e.g. a torch tensor that
+ * a torch.distributed / RCCL gather then sends): copies local_pixel_count float4, zero-fills up to capacity_float4 */
+int adypt_copy_local_radiance(adypt_ctx *ctx, void *dst_device, int64_t capacity_float4);
 /* blocks owned by `rank` out of `nranks` for a width x height image (same function the contexts use) */
 int64_t adypt_shard_block_count(int width, int height, int rank, int nranks);
 /* scatter one rank's compact buffer (host memory, block-major float4) into a W*H*3 host image */

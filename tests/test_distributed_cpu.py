@@ -1,0 +1,89 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard the frame by pixel tile (same ownership function as the HIP
+contexts), render their tiles with the oracle, and assemble the image with the single gather of
+adypt_amd.distributed — the code path bench.py --gpus N uses with the nccl (RCCL) backend."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, spp, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adypt_amd import distributed as D, scenes
+    from oracle import oracle_py as O
+    from tests.helpers import GOLDEN, oracle_scene_from_golden
+    sc = oracle_scene_from_golden("tiny0")
+    cam = scenes._SCENE_TABLE["tiny0"][3]
+    ip, iv = O.camera(cam["fov"], cam["yaw"], cam["pitch"], w, h)
+    P = O.make_params(w, h, cam["position"], ip, iv, stack_size=16, max_bounce=4)
+    sm = np.fromfile(os.path.join(GOLDEN, "sobol_matrices_64x32.u32"), dtype=np.uint32).reshape(64, 32)
+    st = O.PathTracerState(w, h)
+    stats = O.pt_frames(sc, P, O.shift_bytes(11, w, h), sm, st, spp, mask=D.owner_mask(w, h, rank, world), n_threads=2)
+    local = D.tile_from_image(st.accum, rank, world).reshape(-1)
+    assert local.size == D.block_count(w, h, rank, world) * D.BLOCK_PIXELS * 4
+    pad = np.zeros(D.max_block_count(w, h, world) * D.BLOCK_PIXELS * 4, dtype=np.float32)
+    pad[:local.size] = local
+    rgb = D.gather_radiance(torch.from_numpy(pad), w, h, rank, world)
+    rays = torch.tensor([stats.rays], dtype=torch.int64)
+    dist.all_reduce(rays)  # bench.py sums the units all ranks processed
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # ... and takes the MAX time over ranks
+    assert t.item() == float(world)
+    if rank == 0:
+        np.save(out_path, rgb)
+        np.save(out_path + ".rays.npy", rays.numpy())
+    else:
+        assert rgb is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 100, 75), (2, 64, 64)])
+def test_tile_shard_gather_world2_gloo(world, w, h, tmp_path, sobol_matrices):
+    from adypt_amd import distributed as D, scenes
+    from oracle import oracle_py as O
+    from tests.helpers import oracle_scene_from_golden
+    out = str(tmp_path / "img.npy")
+    spp = 3
+    mp.spawn(_worker, args=(world, _free_port(), w, h, spp, out), nprocs=world, join=True)
+    got = np.load(out)
+    sc = oracle_scene_from_golden("tiny0")
+    cam = scenes._SCENE_TABLE["tiny0"][3]
+    ip, iv = O.camera(cam["fov"], cam["yaw"], cam["pitch"], w, h)
+    P = O.make_params(w, h, cam["position"], ip, iv, stack_size=16, max_bounce=4)
+    st = O.PathTracerState(w, h)
+    stats = O.pt_frames(sc, P, O.shift_bytes(11, w, h), sobol_matrices, st, spp)
+    assert np.array_equal(got.view(np.uint32), st.accum[..., :3].view(np.uint32))  # sharded == single process, bit for bit
+    assert int(np.load(out + ".rays.npy")[0]) == stats.rays
+
+
+def test_ownership_partitions_the_image():
+    from adypt_amd import distributed as D
+    for (w, h, n) in [(1920, 1080, 8), (4096, 4096, 8), (100, 75, 3), (33, 31, 2), (64, 64, 1)]:
+        total = sum(D.owner_mask(w, h, r, n).astype(np.int64) for r in range(n))
+        assert (total == 1).all()
+        counts = [D.block_count(w, h, r, n) for r in range(n)]
+        assert sum(counts) == ((w + 31) // 32) * ((h + 31) // 32)
+        assert max(counts) - min(counts) <= max(2, n // 2)  # balanced
+        img = np.random.RandomState(0).rand(h, w, 4).astype(np.float32)
+        rgb = np.zeros((h, w, 3), np.float32)
+        for r in range(n):
+            D.untile(w, h, r, n, D.tile_from_image(img, r, n), rgb)
+        assert np.array_equal(rgb, img[..., :3])

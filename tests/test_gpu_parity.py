@@ -1,0 +1,237 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same seeded
+inputs and against the committed golden vectors.  Bar: bit-exact — triangle ids, node-visit hashes, u/v/t bit
+patterns, and (thanks to the pinned canonical arithmetic) every accumulated radiance pixel."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from adypt_amd import api, distributed as D, scenes, _native as N  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+from tests.helpers import (GOLDEN, bits, golden_scene, oracle_params_from_config, oracle_scene_from_instance,  # noqa: E402
+                           random_rays)
+
+
+def make_instance(cache, name, w, h, pt=None, seed=99, rank=0, world=1, camera=None):
+    spec = scenes.make_scene(name, cache, width=w, height=h, pt=pt, camera=camera)
+    inst = api.Instance()
+    assert inst.InitializeFromFile(spec.config_path, shift_seed=seed, tile_rank=rank, tile_nranks=world), api.InstanceConfig.last_error()
+    return inst
+
+
+def golden_tracer(name, w=64, h=36, stack=32):
+    _, idx, nodes, tris, mats, woop = golden_scene(name)
+    sc = api.Scene.FromArrays(tris, mats)
+    b = api.WideBVH()
+    b.nodes, b.tri_indices = nodes.view("u1").reshape(-1), idx
+    hs = api.HipScene()
+    hs.Initialize(sc, b, woop=woop)  # the reference's own node / index / Woop arrays go straight into HBM
+    cfg = api.InstanceConfig()
+    p = cfg.pt_params(0)
+    p.stack_size = stack
+    pt = api.HipPathTracer()
+    pt.Initialize(p, hs, w, h)
+    return pt
+
+
+@pytest.mark.parametrize("name", ["tiny0", "tiny1", "tiny2"])
+def test_golden_known_answers_on_reference_built_arrays(name):
+    """G5 through the HIP kernel, fed with the arrays the REFERENCE builder and init_triangles produced."""
+    kat = np.load(os.path.join(GOLDEN, name + "_kat.npz"))
+    pt = golden_tracer(name)
+    hits = pt.TraceRays(kat["rays"], with_stats=True)
+    assert hits.tobytes() == kat["hits"].tobytes()
+    fov, yaw, pitch, px, py, pz = kat["cam"]
+    ip, iv = api.camera_matrices(float(fov), float(yaw), float(pitch), 64, 36)
+    pt.SetCamera(ip, iv, [px, py, pz])
+    pt.Trace(False)
+    tri, uv = pt.ReadHits()
+    ph = kat["primary_hits"]
+    assert np.array_equal(tri, ph["tri_id"])
+    m = ph["tri_id"] >= 0
+    assert np.array_equal(bits(uv[..., 0])[m], bits(ph["u"])[m]) and np.array_equal(bits(uv[..., 1])[m], bits(ph["v"])[m])
+    assert np.array_equal(bits(pt.ReadResult()), bits(kat["primary_rgba"][..., :3]))
+
+
+def test_golden_end_to_end_frame(sobol_matrices):
+    """G6: 32x18, 4 spp with subpixel 2 / tmpLife 2 (primary-hit cache + sub-pixel cadence) == committed oracle frame."""
+    import json
+    pt = golden_tracer("tiny0", 32, 18, stack=16)
+    p = api.InstanceConfig().pt_params(4242)
+    p.stack_size, p.max_bounce, p.subpixel, p.tmp_lifetime, p.ray_tmin, p.clamp = 16, 5, 2, 2, 1e-4, 4.0
+    p.sun[:] = [12.0, 11.0, 10.0]
+    pt.SetConfig(p)
+    cam = scenes._SCENE_TABLE["tiny0"][3]
+    ip, iv = api.camera_matrices(cam["fov"], cam["yaw"], cam["pitch"], 32, 18)
+    pt.SetCamera(ip, iv, cam["position"])
+    pt.SetInstrumentation(counters=True)
+    pt.Trace(True, 4)
+    ref = np.load(os.path.join(GOLDEN, "tiny0_frame_32x18_4spp.npy"))
+    assert np.array_equal(bits(pt.ReadResult()), bits(ref[..., :3]))
+    st, gold = pt.GetStats(), json.load(open(os.path.join(GOLDEN, "tiny0_frame_32x18_4spp.json")))
+    assert (st["rays"], st["nodes_visited"], st["tris_tested"], st["hits"], st["shaded"], st["max_stack"]) == \
+        (gold["rays"], gold["nodes"], gold["tris"], gold["hits"], gold["shaded"], gold["max_depth"])
+    assert pt.GetSPP() == 4
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("tiny2", 96, 64, 3), ("tiny1", 160, 90, 4), ("tiny0", 160, 90, 20), ("sibenik", 160, 90, 4),
+                                          ("sponza", 192, 108, 4), ("tiny0", 100, 75, 5)])
+def test_full_pipeline_bit_exact_vs_oracle(name, w, h, spp, scene_cache, sobol_matrices):
+    inst = make_instance(scene_cache, name, w, h)
+    c, pt = inst.m_config.c, inst.m_path_tracer
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    for vt in (0, 1, 2, 4, 5):  # primaryray.glsl viewer types
+        pt.m_viewer_type = vt
+        pt.Trace(False)
+        rgba, hits, _ = O.primary_frame(osc, P, vt)
+        assert np.array_equal(bits(pt.ReadResult()), bits(rgba[..., :3])), "viewer type %d" % vt
+    tri, uv = pt.ReadHits()
+    assert np.array_equal(tri, hits["tri_id"])
+    rays = random_rays(inst.scene.triangles, 20000, 3)
+    gh, oh = pt.TraceRays(rays, with_stats=True), O.trace(osc, rays, c.stack_size)
+    assert gh.tobytes() == oh.tobytes()  # ids, u/v/t bits, nodes visited, triangles tested, visit hash, max depth
+    gh2 = pt.TraceRays(rays, with_stats=False)
+    assert np.array_equal(gh2["tri_id"], oh["tri_id"]) and np.array_equal(bits(gh2["t"]), bits(oh["t"]))
+    pt.SetInstrumentation(counters=True)
+    pt.ResetStats()
+    pt.Trace(True, spp)
+    st = O.PathTracerState(c.width, c.height)
+    ost = O.pt_frames(osc, P, O.shift_bytes(99, c.width, c.height), sobol_matrices, st, spp).as_dict()
+    assert np.array_equal(bits(pt.ReadResult()), bits(st.accum[..., :3]))
+    g = pt.GetStats()
+    assert (g["rays"], g["nodes_visited"], g["tris_tested"], g["hits"], g["shaded"], g["max_stack"]) == \
+        (ost["rays"], ost["nodes"], ost["tris"], ost["hits"], ost["shaded"], ost["max_depth"])
+    # progressive: more frames continue the same sequence (Sobol stream, spp counter, running mean)
+    pt.Trace(True, 2)
+    O.pt_frames(osc, P, O.shift_bytes(99, c.width, c.height), sobol_matrices, st, 2)
+    assert np.array_equal(bits(pt.ReadResult()), bits(st.accum[..., :3])) and pt.GetSPP() == spp + 2
+    # Trace(false) then Trace(true) restarts the accumulation like the reference (OglPathTracer.cpp:39-46,55-56)
+    pt.Trace(False)
+    assert pt.GetSPP() == 0
+    pt.Trace(True, 1)
+    st1 = O.PathTracerState(c.width, c.height)
+    O.pt_frames(osc, P, O.shift_bytes(99, c.width, c.height), sobol_matrices, st1, 1)
+    assert np.array_equal(bits(pt.ReadResult()), bits(st1.accum[..., :3]))
+
+
+def test_ragged_and_edge_batches(scene_cache):
+    inst = make_instance(scene_cache, "tiny0", 64, 48)
+    pt = inst.m_path_tracer
+    osc = oracle_scene_from_instance(inst)
+    assert len(pt.TraceRays(np.zeros((0, 8), np.float32))) == 0  # empty batch
+    for n in (1, 63, 64, 65, 4097):
+        rays = random_rays(inst.scene.triangles, n, n)
+        assert pt.TraceRays(rays, True).tobytes() == O.trace(osc, rays, inst.m_config.c.stack_size).tobytes()
+    # more rays than the queue capacity (64x48 image -> 4096 slots): chunked internally
+    rays = random_rays(inst.scene.triangles, 3 * 4096 + 17, 5)
+    assert pt.TraceRays(rays, True).tobytes() == O.trace(osc, rays, inst.m_config.c.stack_size).tobytes()
+    # NaN / Inf rays terminate and miss
+    bad = random_rays(inst.scene.triangles, 256, 9)
+    bad[:64, 0] = np.nan
+    bad[64:128, 4] = np.nan
+    bad[128:192, 1] = np.inf
+    bad[192:, 4:7] = 0.0
+    g, o = pt.TraceRays(bad, True), O.trace(osc, bad, inst.m_config.c.stack_size)
+    assert np.array_equal(g["tri_id"], o["tri_id"]) and np.array_equal(g["nodes"], o["nodes"]) and np.array_equal(g["tris"], o["tris"])
+    assert (g["tri_id"][:192] == -1).all()
+
+
+def test_stack_overflow_and_bad_material_are_reported(scene_cache):
+    inst = make_instance(scene_cache, "tiny0", 64, 48, pt={"stackSize": 1})
+    with pytest.raises(N.AdyptError) as e:
+        inst.m_path_tracer.Trace(False)
+    assert e.value.code == N.E_STACK_OVERFLOW
+    # per-ray report in instrumented batches: max_depth = 0xffffffff, same rays as the oracle flags
+    rays = random_rays(inst.scene.triangles, 5000, 1)
+    g, o = inst.m_path_tracer.TraceRays(rays, True), O.trace(oracle_scene_from_instance(inst), rays, 1)
+    assert np.array_equal(g["max_depth"], o["max_depth"]) and (g["max_depth"] == 0xFFFFFFFF).any()
+    # material id -1 (faces before any usemtl, Scene.cpp:52): path ends, counted, no out-of-bounds read
+    _, idx, nodes, tris, mats, woop = golden_scene("tiny1")
+    tris = tris.copy()
+    tris["matid"][::3] = -1
+    tris["matid"][1::7] = 1000
+    sc = api.Scene.FromArrays(tris, mats)
+    b = api.WideBVH()
+    b.nodes, b.tri_indices = nodes.view("u1").reshape(-1), idx
+    hs = api.HipScene()
+    hs.Initialize(sc, b)
+    pt = api.HipPathTracer()
+    pt.Initialize(api.InstanceConfig().pt_params(3), hs, 64, 36)
+    cam = scenes._SCENE_TABLE["tiny1"][3]
+    ip, iv = api.camera_matrices(cam["fov"], cam["yaw"], cam["pitch"], 64, 36)
+    pt.SetCamera(ip, iv, cam["position"])
+    pt.Trace(True, 2)
+    assert pt.GetStats()["bad_materials"] > 0 and np.isfinite(pt.ReadResult()).all()
+
+
+def test_tile_shards_reassemble_bit_exact(scene_cache):
+    """Multi-GPU path on one GPU: contexts with tile_rank r of 3 render their blocks; untiled union == 1-context frame."""
+    w, h, spp = 200, 120, 3
+    full = make_instance(scene_cache, "tiny0", w, h, seed=5)
+    full.m_path_tracer.Trace(True, spp)
+    ref = full.m_path_tracer.ReadResult()
+    out = np.zeros_like(ref)
+    rays = 0
+    for r in range(3):
+        part = make_instance(scene_cache, "tiny0", w, h, seed=5, rank=r, world=3)
+        part.m_path_tracer.Trace(True, spp)
+        assert part.m_path_tracer.local_pixel_count() == D.block_count(w, h, r, 3) * 1024
+        mine = part.m_path_tracer.ReadResult()
+        mask = D.owner_mask(w, h, r, 3).astype(bool)
+        assert (mine[~mask] == 0).all()
+        out[mask] = mine[mask]
+        rays += part.m_path_tracer.GetStats()["rays"]
+    assert np.array_equal(bits(out), bits(ref))
+    assert rays == full.m_path_tracer.GetStats()["rays"]
+
+
+def test_full_size_frame_bit_exact_and_deterministic(scene_cache, sobol_matrices):
+    """BASELINE config 2/3 size (1920x1080, sponza stand-in, 8 bounces): primary hits and one path-traced frame equal
+    the oracle pixel for pixel; re-running gives identical bits; rays are counted exactly."""
+    inst = make_instance(scene_cache, "sponza", 1920, 1080, seed=12345)
+    c, pt = inst.m_config.c, inst.m_path_tracer
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    pt.m_viewer_type = 0
+    pt.Trace(False)
+    rgba, hits, ost = O.primary_frame(osc, P, 0)
+    tri, _ = pt.ReadHits()
+    assert np.array_equal(tri, hits["tri_id"])
+    assert np.array_equal(bits(pt.ReadResult()), bits(rgba[..., :3]))
+    pt.ResetStats()
+    pt.Trace(True, 1)
+    a = pt.ReadResult()
+    st = O.PathTracerState(c.width, c.height)
+    os_ = O.pt_frames(osc, P, O.shift_bytes(12345, c.width, c.height), sobol_matrices, st, 1).as_dict()
+    assert np.array_equal(bits(a), bits(st.accum[..., :3]))
+    assert pt.GetStats()["rays"] == os_["rays"]
+    pt.Reset()
+    pt.Trace(True, 1)
+    assert np.array_equal(bits(pt.ReadResult()), bits(a))
+    # size-independent properties: clamp respected, finite, A never written to RGB, misses carry exactly the sun colour
+    assert np.isfinite(a).all() and a.max() <= c.clamp
+    sky = hits["tri_id"] == -1
+    if sky.any():
+        assert np.array_equal(a[sky], np.broadcast_to(np.minimum(np.array(list(c.sun), np.float32), np.float32(c.clamp)), a[sky].shape))
+
+
+def test_exr_output_of_a_render(scene_cache, tmp_path):
+    inst = make_instance(scene_cache, "tiny0", 96, 64)
+    inst.m_path_tracer.Trace(True, 2)
+    p = str(tmp_path / "r.exr")
+    inst.m_path_tracer.SaveResult(p, False)
+    assert np.array_equal(bits(api.load_exr(p)), bits(inst.m_path_tracer.ReadResult()))
+
+
+def test_cli_headless_instance(scene_cache, tmp_path):
+    import subprocess
+    spec = scenes.make_scene("tiny0", scene_cache, width=64, height=48)
+    exe = os.path.join(os.path.dirname(N.LIB_PATH), "adypt_hip")
+    out = str(tmp_path / "cli.exr")
+    r = subprocess.run([exe, spec.config_path, "--spp", "3", "--out", out, "--seed", "77"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()
+    inst = api.Instance()
+    assert inst.InitializeFromFile(spec.config_path, shift_seed=77)
+    inst.m_path_tracer.Trace(True, 3)
+    assert np.array_equal(bits(api.load_exr(out)), bits(inst.m_path_tracer.ReadResult()))

@@ -1,0 +1,164 @@
+"""Product host code (libadypt_hip.so, include/adypt_host.h) against the reference's outputs: OBJ loader, material
+conversion, SBVH + CWBVH8 builders (bit-identical .bvh), .config reader/writer, Sobol, shift bytes, camera, EXR."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from adypt_amd import api, scenes
+from oracle import oracle_py as O
+from tests.helpers import GOLDEN, bits, golden_scene
+
+
+@pytest.mark.parametrize("name", ["tiny0", "tiny1", "tiny2"])
+def test_loader_and_builder_reproduce_reference_arrays(name, tmp_path):
+    _, idx, nodes, tris, mats, woop = golden_scene(name)
+    sc = api.Scene()
+    assert sc.LoadFromFile(os.path.join(GOLDEN, name + ".obj"))
+    assert sc.triangles.tobytes() == tris.tobytes()
+    assert sc.materials.tobytes() == mats.tobytes()
+    cfg = api.InstanceConfig()
+    b = api.WideBVH()
+    b.Build(sc, cfg.bvh_params())
+    assert b.nodes.tobytes() == nodes.tobytes()
+    assert np.array_equal(b.tri_indices, idx)
+    out = str(tmp_path / "x.bvh")
+    assert b.SaveToFile(out, cfg.bvh_params())
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, name + ".bvh"), "rb").read()
+    assert np.array_equal(bits(api.woop_matrices(sc.triangles, b.tri_indices)), bits(woop))
+    # cache semantics (src/BVH/WideBVH.cpp:42-45): a .bvh built with other parameters is rejected
+    b2 = api.WideBVH()
+    assert b2.LoadFromFile(out, cfg.bvh_params())
+    other = cfg.bvh_params()
+    other.triangle_sah = 0.5
+    assert not api.WideBVH().LoadFromFile(out, other)
+
+
+@pytest.mark.parametrize("name", ["sibenik", "sponza"])
+def test_large_standin_bvh_hash_equals_reference(name, scene_cache):
+    """config 1: the ~75k / ~250k triangle stand-ins through loader + SBVH + CWBVH8 -> SHA-256 of the reference's .bvh."""
+    ref = json.load(open(os.path.join(GOLDEN, "bvh_sha256.json")))[name]
+    spec = scenes.make_scene(name, scene_cache)
+    assert spec.n_tris == ref["n_tris"]
+    if hashlib.sha256(open(spec.obj_path, "rb").read()).hexdigest() != ref["obj_sha256"]:
+        pytest.skip("procedural OBJ text differs on this numpy build; hash pin not applicable")
+    sc = api.Scene()
+    assert sc.LoadFromFile(spec.obj_path)
+    cfg = api.InstanceConfig()
+    b = api.WideBVH()
+    b.Build(sc, cfg.bvh_params())
+    out = os.path.join(scene_cache, name + "_test.bvh")
+    assert b.SaveToFile(out, cfg.bvh_params())
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == ref["bvh_sha256"]
+
+
+def test_config_cases_match_reference_parser_and_writer(tmp_path):
+    cases = json.load(open(os.path.join(GOLDEN, "config_cases.json")))
+    assert cases["good"]["accepted"] and not cases["int_literal_float"]["accepted"]
+    for name, c in cases.items():
+        cfg = api.InstanceConfig()
+        ok = cfg.Parse(c["input"])
+        assert ok == c["accepted"], "%s: reference %s, product %s (%s)" % (name, c["accepted"], ok, cfg.last_error())
+        if ok:
+            assert cfg.GetJson() == c["json"], name
+            # write -> read -> write is a fixed point
+            p = str(tmp_path / (name + ".config"))
+            assert cfg.SaveToFile(p)
+            cfg2 = api.InstanceConfig()
+            assert cfg2.LoadFromFile(p) and cfg2.GetJson() == c["json"]
+    missing = api.InstanceConfig()
+    assert not missing.Parse(cases["good"]["input"].replace('"stackSize": 24,', ""))
+    assert "stackSize" in missing.last_error()
+    assert not api.InstanceConfig().LoadFromFile("/nonexistent/file.config")
+
+
+def test_sobol_shift_camera_host_functions(sobol_matrices):
+    ref = np.fromfile(os.path.join(GOLDEN, "sobol_points_1000x16.f32"), dtype=np.float32).reshape(1000, 16)
+    assert np.array_equal(bits(api.sobol_points(16, 0, 1000)), bits(ref))
+    assert np.array_equal(bits(api.sobol_points(10, 123, 7)), bits(ref[123:130, :10]))
+    assert np.array_equal(bits(api.sobol_points(64, 5, 3)), bits(O.sobol(sobol_matrices, 64, 5, 3)))
+    for seed in (0, 1, 4242, 0xFFFFFFFF):
+        assert np.array_equal(api.shift_bytes(seed, 37, 11), O.shift_bytes(seed, 37, 11))  # own MT19937 vs std::mt19937
+    cams = json.load(open(os.path.join(GOLDEN, "camera_cases.json")))
+    cref = np.fromfile(os.path.join(GOLDEN, "camera_cases.f32"), dtype=np.float32).reshape(len(cams), 32)
+    for c, r in zip(cams, cref):
+        ip, iv = api.camera_matrices(*c)
+        assert np.array_equal(bits(ip), bits(r[:16])) and np.array_equal(bits(iv), bits(r[16:]))
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_exr_writer_decodes_like_tinyexr_output(fp16, tmp_path):
+    img = np.fromfile(os.path.join(GOLDEN, "exr_input_52x40.rgbf32"), dtype=np.float32).reshape(40, 52, 3)
+    ref = np.fromfile(os.path.join(GOLDEN, "exr_ref_decoded_fp%d.rgbaf32" % (16 if fp16 else 32)), dtype=np.float32).reshape(40, 52, 4)
+    p = str(tmp_path / "o.exr")
+    api.save_exr(p, img, fp16)
+    back = api.load_exr(p)
+    # same pixels as the reference's SaveEXR -> LoadEXR (identical half rounding)
+    assert np.array_equal(bits(back), bits(ref[..., :3]))
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"\x76\x2f\x31\x01" and b"compression\x00compression\x00\x01\x00\x00\x00\x03" in raw
+    assert raw.index(b"B\x00") < raw.index(b"G\x00") < raw.index(b"R\x00")  # channel order B, G, R
+    if O.have_ref():  # build container: let the reference's tinyexr decode the file we wrote
+        out = str(tmp_path / "dec.bin")
+        r = O.ref("exrload", p, out, capture=True)
+        assert r.returncode == 0, r.stderr
+        dec = np.fromfile(out, dtype=np.float32).reshape(40, 52, 4)
+        assert np.array_equal(bits(dec[..., :3]), bits(ref[..., :3]))
+    small = np.ones((8, 8, 3), np.float32)
+    api.save_exr(str(tmp_path / "s.exr"), small, fp16)  # < 16x16: stored uncompressed like tinyexr
+    assert np.array_equal(api.load_exr(str(tmp_path / "s.exr")), small)
+
+
+def test_obj_loader_edge_cases(tmp_path):
+    """quads (ear clipping), negative indices, missing normals/uvs, faces before usemtl (matid -1), odd numbers."""
+    obj = tmp_path / "e.obj"
+    (tmp_path / "e.mtl").write_text("newmtl a\nKd 0.1 0.2 0.3\nillum 2\nNs 50\n\nnewmtl b\nKe 1 2 3\n")
+    obj.write_text("mtllib e.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv .5 5e-1 1.5E0\nvn 0 0 1\nvt 0.25 0.75\n"
+                   "f 1 2 3\nusemtl a\nf 1//1 2//1 3//1 4//1\nusemtl b\nf -5/1 -4/1 -1/1\nusemtl nope\nf 1 2 4\n")
+    sc = api.Scene()
+    assert sc.LoadFromFile(str(obj))
+    t = np.frombuffer(sc.triangles.tobytes(), dtype=O.TRI_DT)
+    assert len(t) == 5
+    assert list(t["matid"]) == [-1, 0, 0, 1, -1]
+    assert np.allclose(t["n"][0], [[0, 0, 1]] * 3)            # generated flat normal
+    assert t["p"][3][2].tolist() == [0.0, 0.5, 1.5]           # ".5" is rejected by the parser recipe -> 0, "5e-1" -> 0.5
+    assert t["tc"][3][0].tolist() == [0.25, 0.25]             # v flipped: 1 - 0.75
+    m = np.frombuffer(sc.materials.tobytes(), dtype=O.MAT_DT)
+    assert m["illum"].tolist() == [2, 0] and m["dtex"].tolist() == [-1, -1] and m["shininess"][0] == 50
+    if O.have_ref():
+        r = O.ref("scene", str(obj), str(tmp_path / "r.tris"), str(tmp_path / "r.mats"), capture=True)
+        assert r.returncode == 0
+        assert open(tmp_path / "r.tris", "rb").read() == sc.triangles.tobytes()
+        assert open(tmp_path / "r.mats", "rb").read() == sc.materials.tobytes()
+
+
+def test_texture_decoders(tmp_path):
+    import struct
+    import zlib
+    rs = np.random.RandomState(3)
+    img = rs.randint(0, 256, size=(5, 7, 3)).astype(np.uint8)
+    (tmp_path / "t.ppm").write_bytes(b"P6\n# c\n7 5\n255\n" + img.tobytes())
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(5))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    (tmp_path / "t.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 7, 5, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    row = (7 * 3 + 3) & ~3
+    bmp = b"".join(img[4 - y, :, ::-1].tobytes() + b"\x00" * (row - 21) for y in range(5))
+    (tmp_path / "t.bmp").write_bytes(b"BM" + struct.pack("<IHHI", 54 + len(bmp), 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 7, 5, 1, 24, 0, len(bmp), 0, 0, 0, 0) + bmp)
+    (tmp_path / "t.tga").write_bytes(struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, 7, 5, 24, 0x20) + img[:, :, ::-1].tobytes())
+    for ext in ("ppm", "png", "bmp", "tga"):
+        (tmp_path / ("m_%s.mtl" % ext)).write_text("newmtl x\nmap_Kd t.%s\n" % ext)
+        (tmp_path / ("o_%s.obj" % ext)).write_text("mtllib m_%s.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl x\nf 1 2 3\n" % ext)
+        sc = api.Scene()
+        assert sc.LoadFromFile(str(tmp_path / ("o_%s.obj" % ext)))
+        assert len(sc.textures) == 1 and np.array_equal(sc.textures[0], img), ext
+        assert np.frombuffer(sc.materials.tobytes(), dtype=O.MAT_DT)["dtex"][0] == 0
+    (tmp_path / "m_bad.mtl").write_text("newmtl x\nKd 1 1 1\nmap_Kd missing.png\n")
+    (tmp_path / "o_bad.obj").write_text("mtllib m_bad.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl x\nf 1 2 3\n")
+    sc = api.Scene()
+    assert sc.LoadFromFile(str(tmp_path / "o_bad.obj"))
+    m = np.frombuffer(sc.materials.tobytes(), dtype=O.MAT_DT)
+    assert m["dtex"][0] == -1 and m["kd"][0].tolist() == [0, 0, 0]  # failed load: dtex -1, Kd left zero (OglScene.cpp:60-68)

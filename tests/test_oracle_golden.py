@@ -1,0 +1,116 @@
+"""Pins the oracle (oracle/oracle.cpp) against golden vectors produced by the reference's own CPU code
+(tests/golden/make_golden.py via oracle/_ref) and against an independent fp64 brute force."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+from tests.helpers import GOLDEN, bits, golden_scene, oracle_scene_from_golden
+
+
+@pytest.mark.parametrize("name", ["tiny0", "tiny1", "tiny2"])
+def test_woop_matches_reference_init_triangles(name):
+    _, idx, _, tris, _, woop_ref = golden_scene(name)
+    w = O.woop_matrices(tris, idx)
+    assert np.array_equal(bits(w), bits(woop_ref))
+
+
+def test_camera_matches_reference_glm():
+    cams = json.load(open(os.path.join(GOLDEN, "camera_cases.json")))
+    ref = np.fromfile(os.path.join(GOLDEN, "camera_cases.f32"), dtype=np.float32).reshape(len(cams), 32)
+    for c, r in zip(cams, ref):
+        ip, iv = O.camera(*c)
+        assert np.array_equal(bits(ip), bits(r[:16])) and np.array_equal(bits(iv), bits(r[16:]))
+
+
+def test_sobol_matches_reference_stream(sobol_matrices):
+    ref = np.fromfile(os.path.join(GOLDEN, "sobol_points_1000x16.f32"), dtype=np.float32).reshape(1000, 16)
+    assert np.array_equal(bits(O.sobol(sobol_matrices, 16, 0, 1000)), bits(ref))
+    assert np.array_equal(bits(O.sobol(sobol_matrices, 16, 337, 50)), bits(ref[337:387]))
+    assert ref[0, 0] == 0.5  # first point of the gray-code sequence
+
+
+def test_shift_bytes_are_mt19937_low_bytes():
+    ref = np.fromfile(os.path.join(GOLDEN, "shift_bytes_seed0_seed4242.u8"), dtype=np.uint8).reshape(2, 64)
+    assert np.array_equal(O.shift_bytes(0, 8, 4).reshape(-1), ref[0])
+    assert np.array_equal(O.shift_bytes(4242, 8, 4).reshape(-1), ref[1])
+    # known answer of MT19937 with the default seed 5489: first output 3499211612 -> low byte 0x5c
+    assert O.shift_bytes(5489, 1, 1).reshape(-1)[0] == (3499211612 & 0xFF)
+
+
+@pytest.mark.parametrize("name", ["tiny0", "tiny1", "tiny2"])
+def test_traversal_known_answers(name):
+    kat = np.load(os.path.join(GOLDEN, name + "_kat.npz"))
+    sc = oracle_scene_from_golden(name)
+    hits = O.trace(sc, kat["rays"], 32)
+    assert hits.tobytes() == kat["hits"].tobytes()
+    fov, yaw, pitch, px, py, pz = kat["cam"]
+    ip, iv = O.camera(fov, yaw, pitch, 64, 36)
+    P = O.make_params(64, 36, [px, py, pz], ip, iv, stack_size=32)
+    rgba, phits, _ = O.primary_frame(sc, P, 0)
+    assert phits.tobytes() == kat["primary_hits"].tobytes()
+    assert np.array_equal(bits(rgba), bits(kat["primary_rgba"]))
+
+
+@pytest.mark.parametrize("name", ["tiny0", "tiny1"])
+def test_traversal_agrees_with_fp64_brute_force(name):
+    _, _, _, tris, _, _ = golden_scene(name)
+    sc = oracle_scene_from_golden(name)
+    rs = np.random.RandomState(123)
+    p = tris["p"].reshape(-1, 3)
+    n = 3000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, :3] = rs.uniform(p.min(0) - 1, p.max(0) + 1, size=(n, 3))
+    rays[:, 3] = 1e-4
+    rays[:, 4:7] = rs.normal(size=(n, 3))
+    hits = O.trace(sc, rays, 32)
+    bi, bt = O.brute_force(tris, rays)
+    mism = hits["tri_id"] != bi
+    # a different id is only acceptable for coplanar duplicates / silhouette ties: same distance
+    assert np.all(np.abs(hits["t"][mism].astype(np.float64) - bt[mism]) <= 1e-4 * np.maximum(1.0, np.abs(bt[mism])))
+    assert mism.mean() < 0.01
+    hit = bi >= 0
+    assert np.allclose(hits["t"][hit & ~mism], bt[hit & ~mism], rtol=1e-4, atol=1e-5)
+
+
+def test_end_to_end_frame_golden(sobol_matrices):
+    """G6: 32x18, 4 spp, subpixel 2, tmpLife 2 — exercises the primary-hit cache and sub-pixel cadence."""
+    from adypt_amd import scenes
+    sc = oracle_scene_from_golden("tiny0")
+    cam = scenes._SCENE_TABLE["tiny0"][3]
+    ip, iv = O.camera(cam["fov"], cam["yaw"], cam["pitch"], 32, 18)
+    P = O.make_params(32, 18, cam["position"], ip, iv, stack_size=16, max_bounce=5, subpixel=2, tmp_life=2, tmin=1e-4, clamp=4.0, sun=(12.0, 11.0, 10.0))
+    st = O.PathTracerState(32, 18)
+    stats = O.pt_frames(sc, P, O.shift_bytes(4242, 32, 18), sobol_matrices, st, 4)
+    ref = np.load(os.path.join(GOLDEN, "tiny0_frame_32x18_4spp.npy"))
+    assert np.array_equal(bits(st.accum), bits(ref))
+    assert stats.as_dict() == json.load(open(os.path.join(GOLDEN, "tiny0_frame_32x18_4spp.json")))
+    # frames rendered one at a time (state carried) give the same image as one call
+    st2 = O.PathTracerState(32, 18)
+    for _ in range(4):
+        O.pt_frames(sc, P, O.shift_bytes(4242, 32, 18), sobol_matrices, st2, 1, n_threads=1)
+    assert np.array_equal(bits(st2.accum), bits(ref))
+    # clamp is respected, no NaN
+    assert np.isfinite(st.accum).all() and st.accum[..., :3].max() <= 4.0
+
+
+def test_canonical_sincos_pow_close_to_libm():
+    """The canonical binary64-series functions are (almost always) the correctly rounded binary32 results."""
+    rs = np.random.RandomState(1)
+    x = (rs.uniform(0, 1, 200000).astype(np.float32) * np.float32(6.28318530718)).astype(np.float32)
+    s, c = O.sincos(x)
+    rs64, rc64 = np.sin(x.astype(np.float64)).astype(np.float32), np.cos(x.astype(np.float64)).astype(np.float32)
+    assert (bits(s) != bits(rs64)).mean() < 1e-4 and (bits(c) != bits(rc64)).mean() < 1e-4
+    assert np.abs(s.astype(np.float64) - np.sin(x.astype(np.float64))).max() < 1e-7
+    base = rs.uniform(0, 1, 200000).astype(np.float32)
+    for e in (0.0, 0.5, 2.0, 60.0, 400.0):
+        y = np.full_like(base, np.float32(1.0) / (np.float32(e) + np.float32(1.0)))
+        p = O.pow_(base, y)
+        ref = np.power(base.astype(np.float64), y.astype(np.float64)).astype(np.float32)
+        assert (bits(p) != bits(ref)).mean() < 1e-4
+    # exponent 1 must be the identity (diffuse sampling: pow(1 - r.y, 1/(0+1)))
+    assert np.array_equal(bits(O.pow_(base, np.ones_like(base))), bits(base))
+    assert np.isnan(O.pow_(np.array([-0.5], np.float32), np.array([0.3], np.float32))[0])
+    assert O.pow_(np.array([0.0], np.float32), np.array([0.3], np.float32))[0] == 0.0
