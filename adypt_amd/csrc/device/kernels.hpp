@@ -345,22 +345,43 @@ __device__ __forceinline__ F3 camera_dir(const FrameArgs &f, int px, int py, flo
 	return normalize3(r);
 }
 
-// wave-level stream compaction: returns this lane's output slot (valid only if `alive`)
+constexpr int kShadeThreads = 1024;            // 16 waves per workgroup: one queue-tail atomic per 1024 paths
+
+// workgroup-level stream compaction: returns this thread's output slot (valid only if `alive`).
+// One device atomic per workgroup — a single queue-tail word saturates at ~88 atomics/us (MI355X_MICROARCH price
+// list, "dequeue"), so a per-wave atomic (32 k per 2 M-path launch) alone would cost ~0.37 ms per kernel.
 __device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t *counter)
 {
+	__shared__ uint32_t wave_base[kShadeThreads / 64];
 	const unsigned long long mask = __ballot(alive);
-	const uint32_t n = (uint32_t)__popcll(mask);
-	const int lane = threadIdx.x & 63;
-	uint32_t base = 0;
-	if(n != 0 && lane == (int)__builtin_ctzll(mask)) base = atomicAdd(counter, n);
-	base = __shfl(base, n != 0 ? (int)__builtin_ctzll(mask) : 0);
-	return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if(lane == 0) wave_base[wave] = (uint32_t)__popcll(mask);
+	__syncthreads();
+	if(threadIdx.x < 64)
+	{
+		const int nw = blockDim.x >> 6;
+		const uint32_t cnt = lane < nw ? wave_base[lane] : 0u;
+		// inclusive scan over (at most 16) wave counts within the first wave
+		uint32_t incl = cnt;
+		for(int off = 1; off < 16; off <<= 1)
+		{
+			const uint32_t up = __shfl_up(incl, off);
+			if(lane >= off) incl += up;
+		}
+		const uint32_t total = __shfl(incl, nw - 1);
+		uint32_t base = 0;
+		if(lane == 0 && total != 0) base = atomicAdd(counter, total);
+		base = __shfl(base, 0);
+		if(lane < nw) wave_base[lane] = base + incl - cnt;
+	}
+	__syncthreads();
+	return wave_base[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
 // use_cache: the frame reuses the cached primary hit (spp % tmpLife != 0, pathtracer.glsl:115-120) — the hit
 // record is copied next to the ray and the host skips the bounce-0 traversal launch.
 // bias_mode 0: Camera() of primaryray.glsl (no sub-pixel bias); 1: Camera(SubPixel()) of pathtracer.glsl
-__global__ __launch_bounds__(256) void k_gen_primary(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int use_cache, int bias_mode)
+__global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int use_cache, int bias_mode)
 {
 	const int L = blockIdx.x * blockDim.x + threadIdx.x;
 	int x = 0, y = 0;
@@ -454,7 +475,7 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 
 // One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for every live path.
 // store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
-__global__ __launch_bounds__(256) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int b, int store_cache)
+__global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int b, int store_cache)
 {
 	const uint32_t n_in = *q.count_in;
 	const uint32_t slot_in = blockIdx.x * blockDim.x + threadIdx.x;

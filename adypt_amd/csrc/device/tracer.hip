@@ -501,11 +501,11 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	FrameArgs f; SceneArgs sc; PixelArgs px;
 	fill_frame(c, &f); fill_scene(c, &sc); fill_pixels(c, &px);
 	HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
-	const int grid = (c->n_local_px + 255) / 256;
+	const int grid = (c->n_local_px + 255) / 256, grid_c = (c->n_local_px + kShadeThreads - 1) / kShadeThreads;
 	{
 		QueueArgs q = queue_args(c, 1, &c->d_counters->count[0], &c->d_counters->count[0]); // writes queue 0
 		hipEvent_t *stop = begin_timing(c, 1);
-		hipLaunchKernelGGL(k_gen_primary, dim3(grid), dim3(256), 0, c->stream, f, sc, q, px, 0, 0);
+		hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 0);
 		end_timing(c, stop);
 	}
 	r = launch_trace(c, 0, &c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr);
@@ -529,7 +529,7 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 	HIP_TRY(c, hipSetDevice(c->device));
 	SceneArgs sc; PixelArgs px;
 	fill_scene(c, &sc); fill_pixels(c, &px);
-	const int grid = (c->n_local_px + 255) / 256;
+	const int grid = (c->n_local_px + 255) / 256, grid_c = (c->n_local_px + kShadeThreads - 1) / kShadeThreads;
 	const bool stats = (c->instrumentation & 2) != 0;
 	for(int s = 0; s < n_spp; ++s)
 	{
@@ -557,7 +557,7 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 		{
 			QueueArgs q = queue_args(c, 1, &c->d_counters->count[0], &c->d_counters->count[0]); // out = queue 0
 			hipEvent_t *stop = begin_timing(c, 1);
-			hipLaunchKernelGGL(k_gen_primary, dim3(grid), dim3(256), 0, c->stream, f, sc, q, px, use_cache, 1);
+			hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, use_cache, 1);
 			end_timing(c, stop);
 		}
 		for(int b = 0; b < max_bounce; ++b)
@@ -570,7 +570,7 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 			}
 			QueueArgs q = queue_args(c, in, &c->d_counters->count[b], &c->d_counters->count[b + 1]);
 			hipEvent_t *stop = begin_timing(c, 1);
-			hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, c->stream, f, sc, q, px, b, (b == 0 && !use_cache) ? 1 : 0);
+			hipLaunchKernelGGL(k_shade, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, b, (b == 0 && !use_cache) ? 1 : 0);
 			end_timing(c, stop);
 		}
 		HIP_TRY(c, hipGetLastError());

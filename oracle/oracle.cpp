@@ -23,7 +23,8 @@
 //        - fused multiply-add ONLY where fmaf() is written (built with -ffp-contract=off);
 //        - dot3(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x));  normalize(v) = v * (1/sqrt(dot3(v,v)));
 //        - sin/cos/pow: fixed IEEE binary64 series (below), rounded once to binary32;
-//        - GLSL min/max NaN rule:  min(x,y) = y<x ? y : x,  max(x,y) = x<y ? y : x.
+//        - min/max: GLSL rule min(x,y) = y<x ? y : x, max(x,y) = x<y ? y : x in shading code; the slab test of the
+//          traversal uses IEEE maxNum/minNum (same values for non-NaN inputs; NaN inputs are undefined in GLSL).
 // =====================================================================================================
 #include <atomic>
 #include <cmath>
@@ -304,8 +305,10 @@ static void bvh_intersect(const OrcScene &sc, int stack_size, const float o4[4],
 				float txmax = fmaf((float)hix[i], adj_idir_x, adj_org.x);
 				float tymax = fmaf((float)hiy[i], adj_idir_y, adj_org.y);
 				float tzmax = fmaf((float)hiz[i], adj_idir_z, adj_org.z);
-				float ctmin = gl_max(gl_max(txmin, tymin), gl_max(tzmin, hit_tmin));    // :128-129
-				float ctmax = gl_min(gl_min(txmax, tymax), gl_min(tzmax, hit_t));
+				// :128-129.  GLSL leaves min/max of NaN undefined; the canonical choice is IEEE-754 maxNum/minNum
+				// (fmaxf/fminf = gfx950 v_max_f32/v_min_f32), identical to the GLSL rule for every non-NaN input.
+				float ctmin = fmaxf(fmaxf(txmin, tymin), fmaxf(tzmin, hit_tmin));
+				float ctmax = fminf(fminf(txmax, tymax), fminf(tzmax, hit_t));
 				if(ctmin <= ctmax) hitmask |= child_bits << bit_index;                  // :130
 			}
 			(void)octinv4;
