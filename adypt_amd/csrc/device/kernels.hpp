@@ -22,7 +22,7 @@ constexpr int kBlockShift = 5;                 // 32x32 pixel shard blocks
 constexpr int kBlockDim = 1 << kBlockShift;
 constexpr int kBlockPixels = kBlockDim * kBlockDim;
 constexpr int kTraceThreads = 256;             // 4 waves per workgroup
-constexpr int kLdsStackMax = 16;               // stack entries kept in LDS per lane; deeper entries spill to HBM
+constexpr int kLdsStackMax = 8;                // stack entries kept in LDS per lane; deeper entries spill to HBM
 constexpr int kNumSegments = 8;                // one ray-queue segment per XCD
 
 struct DeviceCounters {                        // zeroed at the start of every frame / batch
@@ -79,7 +79,7 @@ __device__ __forceinline__ bool fetch_batch(uint32_t *cursor, uint32_t count, ui
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
+__global__ __launch_bounds__(kTraceThreads) void k_trace_v1(TraceArgs a)
 {
 	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64]
 	const int lane = threadIdx.x & 63;

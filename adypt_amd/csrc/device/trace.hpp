@@ -1,0 +1,298 @@
+// k_trace — persistent wave64 CWBVH8 closest-hit traversal for gfx950 (the hot kernel).
+//
+// Semantics: exactly BVHIntersection of shaders/traversal.glsl:14-255 — same node-visit order, same triangle test
+// order, same arithmetic (canon_math.hpp) — so hit ids, u/v/t bits and the visit hash equal the oracle's.
+// What is re-designed for the machine (none of it changes a result):
+//   * persistent waves with per-lane ray replacement: a lane whose ray has finished is refilled from the ray queue
+//     as soon as >= kRefillMin lanes of its wave are idle (wave vote with __ballot / __popcll, one queue atomic per
+//     refill), instead of the whole wave waiting for its slowest ray (measured SIMT utilisation of the
+//     batch-synchronous version: 19 %).
+//   * software-pipelined node fetch: which node comes next (closest remaining child of the current group, or the
+//     popped group) is decided by the *previous* slab test and does not depend on the triangle tests in between, so
+//     its 5 x 16-byte loads are issued before the triangle tests of the current node and their latencies overlap.
+//     Triangles are fetched two at a time for the same reason.  The slab test itself still runs after the triangle
+//     tests (it needs the shortened hit_t), exactly like the reference.
+//   * the node-group stack lives in LDS, laid out [depth][lane] (ds_write_b64 / ds_read_b64, conflict free); only
+//     entries deeper than kLdsStackMax spill to a global scratch array.  Overflow beyond stackSize is reported.
+//   * XCD-aware queue segments (see fetch_rays).
+#pragma once
+#include "kernels.hpp"
+
+namespace adypt {
+
+constexpr int kRefillMin = 16; // refill when at least this many lanes of the wave are idle (or all are)
+
+// Grab up to `want` consecutive rays.  The queue is cut into kNumSegments contiguous segments; a workgroup first
+// drains the segment of "its" XCD (workgroups are dealt round-robin over the 8 XCDs, so blockIdx & 7 groups the
+// workgroups that share an L2 — a speed hint only), then steals from the other segments.
+__device__ __forceinline__ uint32_t fetch_rays(uint32_t *cursor, uint32_t count, uint32_t seg_size, int home, uint32_t want, uint32_t *begin)
+{
+	for(int k = 0; k < kNumSegments; ++k)
+	{
+		const int s = (home + k) & (kNumSegments - 1);
+		const uint32_t seg_begin = min((uint32_t)s * seg_size, count);
+		const uint32_t seg_len = min(seg_begin + seg_size, count) - seg_begin;
+		if(seg_len == 0) continue;
+		if(__hip_atomic_load(&cursor[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seg_len) continue;
+		const uint32_t rel = atomicAdd(&cursor[s], want);
+		if(rel < seg_len)
+		{
+			*begin = seg_begin + rel;
+			return min(want, seg_len - rel);
+		}
+	}
+	return 0;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
+{
+	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64]
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
+	const uint32_t total_lanes = gridDim.x * blockDim.x;
+	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+
+	const uint32_t count = *a.count;
+	const uint32_t seg_size = (((count + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
+	const int home = blockIdx.x & (kNumSegments - 1);
+	if(blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats->rays, (unsigned long long)count);
+
+	// per-lane ray state
+	bool active = false;
+	uint32_t ray = 0;
+	F3 origin = f3(0, 0, 0), dir = f3(0, 0, 1), idir = f3(0, 0, 1);
+	bool nx = false, ny = false, nz = false;
+	uint32_t octinv = 7u;
+	float tmin = 0.0f, hit_t = 1e9f, hit_u = 0.0f, hit_v = 0.0f;
+	int32_t hit_idx = -1;
+	int sp = 0;
+	uint32_t ng_x = 0, ng_y = 0, tg_x = 0, tg_y = 0;
+	uint32_t n_nodes = 0, n_tris = 0, hash = 0, max_depth = 0;
+	bool overflow = false;
+
+	unsigned long long st_nodes = 0, st_tris = 0, st_hits = 0;
+	uint32_t st_maxdepth = 0;
+	bool any_overflow = false, exhausted = false;
+
+	for(;;)
+	{
+		// ---------------- refill idle lanes ----------------
+		const unsigned long long idle = __ballot(!active);
+		const uint32_t n_idle = (uint32_t)__popcll(idle);
+		if(!exhausted && (n_idle >= (uint32_t)kRefillMin))
+		{
+			uint32_t begin = 0, got = 0;
+			if(lane == 0) got = fetch_rays(a.cursor, count, seg_size, home, n_idle, &begin);
+			got = __builtin_amdgcn_readfirstlane(got);
+			begin = __builtin_amdgcn_readfirstlane(begin);
+			if(got == 0) exhausted = true;
+			const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+			if(!active && my_rank < got)
+			{
+				// ---- ray setup (traversal.glsl:16-35) ----
+				ray = begin + my_rank;
+				const float4 ro = a.ray_o[ray];
+				const float4 rd = a.ray_d[ray];
+				const float ooeps = __uint_as_float((127u - 64u) << 23);
+				dir = f3(rd.x, rd.y, rd.z);
+				dir.x = fabsf(dir.x) > ooeps ? dir.x : (dir.x >= 0 ? ooeps : -ooeps);
+				dir.y = fabsf(dir.y) > ooeps ? dir.y : (dir.y >= 0 ? ooeps : -ooeps);
+				dir.z = fabsf(dir.z) > ooeps ? dir.z : (dir.z >= 0 ? ooeps : -ooeps);
+				dir = normalize3(dir);
+				idir = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+				nx = dir.x < 0; ny = dir.y < 0; nz = dir.z < 0;
+				octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
+				origin = f3(ro.x, ro.y, ro.z);
+				tmin = ro.w;
+				// make the ray loads complete inside this (rare) refill block: otherwise the compiler's s_waitcnt
+				// bookkeeping carries them into the traversal loop and drains the software-pipelined node fetch
+				asm volatile("" : "+v"(origin.x), "+v"(origin.y), "+v"(origin.z), "+v"(tmin));
+				hit_t = 1e9f; hit_u = 0.0f; hit_v = 0.0f; hit_idx = -1;
+				sp = 0;
+				ng_x = 0; ng_y = 0x80000000u; tg_x = 0; tg_y = 0;
+				if(STATS) { n_nodes = 0; n_tris = 0; hash = 0x811c9dc5u; max_depth = 0; }
+				overflow = false;
+				active = true;
+			}
+		}
+		if(__ballot(active) == 0ull)
+		{
+			if(exhausted) break;
+			continue; // fewer than kRefillMin idle is impossible here (all 64 are idle), so this only repeats after a failed steal
+		}
+
+		if(active)
+		{
+			// ---------------- A. choose the next node (traversal.glsl:47-66 / 245-250) ----------------
+			bool have_node = true;
+			if(ng_y <= 0x00ffffffu)
+			{
+				if(sp == 0) have_node = false;
+				else
+				{
+					--sp;
+					const uint2 g = sp < a.lds_depth ? my_stack[sp * 64] : my_spill[(size_t)(sp - a.lds_depth) * total_lanes];
+					ng_x = g.x; ng_y = g.y;
+					// complete the pop here (LDS read, or the rare spill read from global memory) so that no older
+					// memory operation is pending when the triangle / node loads below are issued
+					asm volatile("" : "+v"(ng_x), "+v"(ng_y));
+				}
+			}
+			// ---------------- B. issue every load of this trip back to back: first triangle pair, then the next node ------
+			struct TriPair { float4 p0, p1, p2, q0, q1, q2; uint32_t tri0, tri1; bool two; };
+			auto load_pair = [&](TriPair &t) {
+				const uint32_t b0 = (uint32_t)__builtin_ctz(tg_y);
+				tg_y &= tg_y - 1u;
+				t.two = tg_y != 0;
+				const uint32_t b1 = t.two ? (uint32_t)__builtin_ctz(tg_y) : b0;
+				tg_y &= tg_y - 1u; // no-op when tg_y is already 0
+				t.tri0 = tg_x + b0; t.tri1 = tg_x + b1;
+				const float4 *w0 = a.woop + (size_t)t.tri0 * 3, *w1 = a.woop + (size_t)t.tri1 * 3;
+				t.p0 = w0[0]; t.p1 = w0[1]; t.p2 = w0[2];
+				t.q0 = w1[0]; t.q1 = w1[1]; t.q2 = w1[2];
+			};
+			// Woop test of one triangle (traversal.glsl:219-242)
+			auto test_tri = [&](const float4 &m0, const float4 &m1, const float4 &m2, uint32_t tri) {
+				const float toz = m0.w - dot3(origin, f3(m0.x, m0.y, m0.z));
+				const float tidz = 1.0f / dot3(dir, f3(m0.x, m0.y, m0.z));
+				const float tt = toz * tidz;
+				const float tu = fmaf(tt, dot3(dir, f3(m1.x, m1.y, m1.z)), m1.w + dot3(origin, f3(m1.x, m1.y, m1.z)));
+				const float tv = fmaf(tt, dot3(dir, f3(m2.x, m2.y, m2.z)), m2.w + dot3(origin, f3(m2.x, m2.y, m2.z)));
+				if(tt > tmin && tt < hit_t && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f)
+				{
+					hit_t = tt; hit_u = tu; hit_v = tv; hit_idx = (int32_t)tri;
+				}
+			};
+			const bool has_tri = tg_y != 0;
+			TriPair tp;
+			tp.p0 = tp.p1 = tp.p2 = tp.q0 = tp.q1 = tp.q2 = make_float4(0, 0, 0, 0); tp.tri0 = tp.tri1 = 0; tp.two = false;
+			if(has_tri) load_pair(tp);
+			uint32_t node = 0;
+			uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0, n4 = n0;
+			if(have_node)
+			{
+				const uint32_t imask = ng_y;
+				const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng_y);
+				ng_y &= ~(1u << bit);
+				if(ng_y > 0x00ffffffu)
+				{
+					if(sp < a.stack_size)
+					{
+						if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);
+						else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);
+						++sp;
+						if(STATS) max_depth = max(max_depth, (uint32_t)sp);
+					}
+					else overflow = true;
+				}
+				const uint32_t slot = (bit - 24u) ^ octinv;
+				node = ng_x + (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
+				const uint4 *np = a.nodes + (size_t)node * 5;
+				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
+			}
+			__builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting arithmetic between the load issues
+
+			// ---------------- C. triangles of the node visited last (traversal.glsl:213-243), two per trip ----------------
+			if(has_tri)
+			{
+				for(;;)
+				{
+					test_tri(tp.p0, tp.p1, tp.p2, tp.tri0);
+					if(tp.two) test_tri(tp.q0, tp.q1, tp.q2, tp.tri1);
+					if(STATS) n_tris += tp.two ? 2u : 1u;
+					if(tg_y == 0) break;
+					load_pair(tp);
+				}
+			}
+
+			if(have_node)
+			{
+				// ---------------- D. slab tests of the fetched node (traversal.glsl:69-205) ----------------
+				if(STATS) { ++n_nodes; hash = (hash * 0x01000193u) ^ node; }
+				const uint32_t octinv4 = octinv * 0x01010101u;
+				const uint32_t head_w = n0.w;
+				const float aix = __uint_as_float((head_w & 0xffu) << 23) * idir.x;
+				const float aiy = __uint_as_float(((head_w >> 8) & 0xffu) << 23) * idir.y;
+				const float aiz = __uint_as_float(((head_w >> 16) & 0xffu) << 23) * idir.z;
+				const float aox = (__uint_as_float(n0.x) - origin.x) * idir.x;
+				const float aoy = (__uint_as_float(n0.y) - origin.y) * idir.y;
+				const float aoz = (__uint_as_float(n0.z) - origin.z) * idir.z;
+				ng_x = n1.x;
+				tg_x = n1.y;
+				uint32_t hitmask = 0;
+#pragma unroll
+				for(int g = 0; g < 2; ++g)
+				{
+					const uint32_t meta4 = g ? n1.w : n1.z;
+					const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+					const uint32_t bit_index4 = (meta4 ^ (octinv4 & ((is_inner4 >> 4) * 0xffu))) & 0x1f1f1f1fu;
+					const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+					const uint32_t qlox = g ? n2.y : n2.x, qloy = g ? n2.w : n2.z, qloz = g ? n3.y : n3.x;
+					const uint32_t qhix = g ? n3.w : n3.z, qhiy = g ? n4.y : n4.x, qhiz = g ? n4.w : n4.z;
+					const uint32_t slox = nx ? qhix : qlox, shix = nx ? qlox : qhix;
+					const uint32_t sloy = ny ? qhiy : qloy, shiy = ny ? qloy : qhiy;
+					const uint32_t sloz = nz ? qhiz : qloz, shiz = nz ? qloz : qhiz;
+#pragma unroll
+					for(int j = 0; j < 4; ++j)
+					{
+						const int sh = 8 * j;
+						const float txmin = fmaf((float)((slox >> sh) & 0xffu), aix, aox);
+						const float tymin = fmaf((float)((sloy >> sh) & 0xffu), aiy, aoy);
+						const float tzmin = fmaf((float)((sloz >> sh) & 0xffu), aiz, aoz);
+						const float txmax = fmaf((float)((shix >> sh) & 0xffu), aix, aox);
+						const float tymax = fmaf((float)((shiy >> sh) & 0xffu), aiy, aoy);
+						const float tzmax = fmaf((float)((shiz >> sh) & 0xffu), aiz, aoz);
+						const float cmin = fmaxf(fmaxf(txmin, tymin), fmaxf(tzmin, tmin));   // IEEE maxNum / minNum
+						const float cmax = fminf(fminf(txmax, tymax), fminf(tzmax, hit_t));
+						if(cmin <= cmax) hitmask |= ((child_bits4 >> sh) & 0xffu) << ((bit_index4 >> sh) & 0xffu);
+					}
+				}
+				ng_y = (hitmask & 0xff000000u) | (head_w >> 24);
+				tg_y = hitmask & 0x00ffffffu;
+			}
+			else
+			{
+				// ---------------- ray finished (traversal.glsl:247-254) ----------------
+				const int32_t tri_id = hit_idx != -1 ? a.tri_indices[hit_idx] : -1;
+				a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
+				any_overflow |= overflow;
+				if(STATS)
+				{
+					if(a.ray_stats)
+					{
+						RayStats rs;
+						rs.ref_idx = hit_idx; rs.nodes = n_nodes; rs.tris = n_tris; rs.hash = hash;
+						rs.max_depth = overflow ? 0xffffffffu : max_depth; rs.pad0 = rs.pad1 = rs.pad2 = 0;
+						a.ray_stats[ray] = rs;
+					}
+					st_nodes += n_nodes; st_tris += n_tris; st_hits += hit_idx != -1 ? 1 : 0;
+					st_maxdepth = max(st_maxdepth, max_depth);
+				}
+				active = false;
+			}
+		}
+	}
+
+	if(any_overflow) atomicAdd(&a.stats->overflows, 1ull);
+	if(STATS)
+	{
+		for(int off = 32; off > 0; off >>= 1)
+		{
+			st_nodes += __shfl_down(st_nodes, off);
+			st_tris += __shfl_down(st_tris, off);
+			st_hits += __shfl_down(st_hits, off);
+			st_maxdepth = max(st_maxdepth, (uint32_t)__shfl_down((int)st_maxdepth, off));
+		}
+		if(lane == 0)
+		{
+			atomicAdd(&a.stats->nodes, st_nodes);
+			atomicAdd(&a.stats->tris, st_tris);
+			atomicAdd(&a.stats->hits, st_hits);
+			atomicMax(&a.stats->max_stack, st_maxdepth);
+		}
+	}
+}
+
+}  // namespace adypt

@@ -5,12 +5,13 @@
 //     memset counters -> k_gen_primary -> [ k_trace -> k_shade ] x maxBounce      (all on ctx->stream, no host sync;
 //     queue sizes live in device memory, the traversal kernel is persistent, the shade grid covers the worst case)
 // There is no CPU fallback anywhere in this file: without a HIP device adypt_create fails with ADYPT_E_NO_DEVICE.
-#include "kernels.hpp"
+#include "trace.hpp"
 #include "../../../include/adypt_hip.h"
 #include "../../../include/adypt_host.h"
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -62,6 +63,7 @@ struct adypt_ctx {
 
 	// launch geometry of the persistent traversal kernel
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0;
+	bool use_v1 = false;
 
 	// state
 	adypt_pt_params params{}, pending{};
@@ -196,7 +198,9 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	c->lds_depth = std::max(1, std::min(stack_size, kLdsStackMax));
 	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	int per_cu = 0;
-	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
+	if(c->use_v1) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_v1<false>, kTraceThreads, lds));
+	else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
+	if(const char *ov = getenv("ADYPT_TRACE_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, atoi(ov)));
 	per_cu = std::max(1, std::min(per_cu, 8));
 	c->trace_blocks = c->num_cus * per_cu;
 	return ensure_spill(c, stack_size);
@@ -217,7 +221,13 @@ int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *curs
 	a.stack_size = stack_size; a.lds_depth = c->lds_depth;
 	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	hipEvent_t *stop = begin_timing(c, 0);
-	if(stats) hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
+	if(c->use_v1)
+	{
+		// batch-synchronous first version, kept for A/B measurements (ADYPT_TRACE_V1=1)
+		if(stats) hipLaunchKernelGGL(k_trace_v1<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
+		else hipLaunchKernelGGL(k_trace_v1<false>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
+	}
+	else if(stats) hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
 	else hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
 	end_timing(c, stop);
 	HIP_TRY(c, hipGetLastError());
@@ -365,6 +375,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	hipDeviceProp_t prop;
 	HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
 	c->num_cus = prop.multiProcessorCount;
+	c->use_v1 = getenv("ADYPT_TRACE_V1") != nullptr;
 
 	c->n_nodes = d->n_nodes; c->n_refs = d->n_refs; c->n_tris = d->n_tris; c->n_mats = d->n_mats; c->n_tex = d->n_textures;
 	c->width = d->width; c->height = d->height; c->rank = d->tile_rank; c->nranks = d->tile_nranks;
