@@ -24,6 +24,7 @@ constexpr int kBlockPixels = kBlockDim * kBlockDim;
 constexpr int kTraceThreads = 256;             // 4 waves per workgroup
 constexpr int kLdsStackMax = 8;                // stack entries kept in LDS per lane; deeper entries spill to HBM
 constexpr int kNumSegments = 8;                // one ray-queue segment per XCD
+constexpr int kCursorStride = 32;              // uint32 words between segment cursors: one 128-byte line each (separate L2 channels)
 
 struct DeviceCounters {                        // zeroed at the start of every frame / batch
 	uint32_t queue_count[2];                   // live rays in queue A / B
@@ -66,8 +67,8 @@ __device__ __forceinline__ bool fetch_batch(uint32_t *cursor, uint32_t count, ui
 		const uint32_t seg_end = min(seg_begin + seg_size, count);
 		if(seg_begin >= seg_end) continue;
 		// cheap pre-check keeps exhausted segments from being hammered with atomics
-		if(__hip_atomic_load(&cursor[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seg_end - seg_begin) continue;
-		const uint32_t rel = atomicAdd(&cursor[s], 64u);
+		if(__hip_atomic_load(&cursor[s * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seg_end - seg_begin) continue;
+		const uint32_t rel = atomicAdd(&cursor[s * kCursorStride], 64u);
 		if(rel < seg_end - seg_begin)
 		{
 			*begin = seg_begin + rel;

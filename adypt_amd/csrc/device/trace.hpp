@@ -21,6 +21,7 @@
 namespace adypt {
 
 constexpr int kRefillMin = 16; // refill when at least this many lanes of the wave are idle (or all are)
+constexpr int kChunk = 128;    // rays reserved per queue atomic (wave-private range, handed out to idle lanes without atomics)
 
 // Grab up to `want` consecutive rays.  The queue is cut into kNumSegments contiguous segments; a workgroup first
 // drains the segment of "its" XCD (workgroups are dealt round-robin over the 8 XCDs, so blockIdx & 7 groups the
@@ -33,8 +34,8 @@ __device__ __forceinline__ uint32_t fetch_rays(uint32_t *cursor, uint32_t count,
 		const uint32_t seg_begin = min((uint32_t)s * seg_size, count);
 		const uint32_t seg_len = min(seg_begin + seg_size, count) - seg_begin;
 		if(seg_len == 0) continue;
-		if(__hip_atomic_load(&cursor[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seg_len) continue;
-		const uint32_t rel = atomicAdd(&cursor[s], want);
+		if(__hip_atomic_load(&cursor[s * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seg_len) continue;
+		const uint32_t rel = atomicAdd(&cursor[s * kCursorStride], want);
 		if(rel < seg_len)
 		{
 			*begin = seg_begin + rel;
@@ -75,19 +76,29 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 	unsigned long long st_nodes = 0, st_tris = 0, st_hits = 0;
 	uint32_t st_maxdepth = 0;
 	bool any_overflow = false, exhausted = false;
+	uint32_t loc_next = 0, loc_end = 0; // wave-uniform: reserved but not yet started rays
 
 	for(;;)
 	{
 		// ---------------- refill idle lanes ----------------
 		const unsigned long long idle = __ballot(!active);
 		const uint32_t n_idle = (uint32_t)__popcll(idle);
-		if(!exhausted && (n_idle >= (uint32_t)kRefillMin))
+		if((!exhausted || loc_next < loc_end) && (n_idle >= (uint32_t)kRefillMin))
 		{
-			uint32_t begin = 0, got = 0;
-			if(lane == 0) got = fetch_rays(a.cursor, count, seg_size, home, n_idle, &begin);
-			got = __builtin_amdgcn_readfirstlane(got);
-			begin = __builtin_amdgcn_readfirstlane(begin);
-			if(got == 0) exhausted = true;
+			if(loc_next == loc_end)
+			{
+				// reserve the next chunk of the queue for this wave: one device atomic per kChunk rays.  (A per-refill
+				// atomic was measured 2.5x slower end to end: all cursors serialise in the L2 atomic unit.)
+				uint32_t cb = 0, cn = 0;
+				if(lane == 0) cn = fetch_rays(a.cursor, count, seg_size, home, (uint32_t)kChunk, &cb);
+				cn = __builtin_amdgcn_readfirstlane(cn);
+				cb = __builtin_amdgcn_readfirstlane(cb);
+				loc_next = cb; loc_end = cb + cn;
+				if(cn == 0) exhausted = true;
+			}
+			const uint32_t begin = loc_next;
+			const uint32_t got = min(n_idle, loc_end - loc_next);
+			loc_next += got;
 			const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
 			if(!active && my_rank < got)
 			{
@@ -119,8 +130,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 		}
 		if(__ballot(active) == 0ull)
 		{
-			if(exhausted) break;
-			continue; // fewer than kRefillMin idle is impossible here (all 64 are idle), so this only repeats after a failed steal
+			if(exhausted && loc_next == loc_end) break;
+			continue;
 		}
 
 		if(active)

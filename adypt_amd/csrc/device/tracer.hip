@@ -24,7 +24,7 @@ constexpr int kMaxBounce = 32;
 
 struct FrameCounters {                 // one memset per frame
 	uint32_t count[kMaxBounce + 1];
-	uint32_t cursor[kMaxBounce + 1][kNumSegments];
+	uint32_t cursor[kMaxBounce + 1][kNumSegments * kCursorStride];
 };
 
 thread_local std::string g_create_error;
@@ -438,6 +438,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	c->pending.ray_tmin = 0.0001f; c->pending.clamp = 4.0f; c->pending.sun[0] = c->pending.sun[1] = c->pending.sun[2] = 0.0f;
 	c->pending.shift_seed = 0;
 	TRY_CREATE(apply_params(c));
+	HIP_CREATE(hipDeviceSynchronize()); // the uploads / memsets above ran on the legacy stream
 	HIP_CREATE(hipStreamSynchronize(c->stream));
 #undef TRY_CREATE
 #undef HIP_CREATE
@@ -690,7 +691,9 @@ int adypt_reset_stats(adypt_ctx *c)
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	harvest_events(c);
-	HIP_TRY(c, hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
+	// on the context's own stream: a legacy-stream hipMemset is not ordered against a non-blocking stream
+	HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(DeviceStats), c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	c->trace_ms = c->shade_ms = 0; c->trace_launches = 0;
 	return ADYPT_OK;
 }
