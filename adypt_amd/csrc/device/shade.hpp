@@ -1,11 +1,16 @@
-// gfx950 kernels of the wavefront path tracer.
+// gfx950 kernels of the wavefront path tracer (everything except the traversal kernel, which lives in trace.hpp).
 //
-//   k_trace<STATS>      persistent wave64 CWBVH8 closest-hit traversal  (shaders/traversal.glsl:14-255)
 //   k_gen_primary       camera rays + path-state init                   (shaders/pathtracer.glsl:206-224, primaryray.glsl:39-49)
 //   k_shade             one bounce of Render(): FetchInfo, scatter, compaction, accumulate on termination
 //                                                                       (shaders/pathtracer.glsl:73-204,224-226)
 //   k_viewer            primary-ray viewer colouring                    (shaders/primaryray.glsl:50-94)
 //   k_untile            compact block-major radiance -> W x H RGB
+//
+// Ray queue = 8 XCD-affine segments.  Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MB
+// L2), so workgroup b of every kernel works on segment b & 7: rays stay with "their" XCD from bounce to bounce, the
+// queue tail of each segment is its own counter on its own 128-byte line (a single tail word saturates at ~88
+// atomics/us on this chip), and one atomic per workgroup appends the survivors.  Segment s owns the slot range
+// [s * seg_cap, (s+1) * seg_cap).  None of this affects results — per-pixel work is independent of slot order.
 //
 // Queue layout (SoA of float4, slot-indexed, rewritten compacted every bounce):
 //   ray_o = (origin.xyz, tmin)      ray_d = (dir.xyz, bits(local pixel))      <- the 32 B the traversal reads
@@ -13,6 +18,8 @@
 //   hit   = (bits(scene triangle id), u, v, t)                                 <- the 16 B the traversal writes
 // Per-local-pixel buffers (block-major, 32x32 blocks of 16 8x8 wave tiles): accum (RGBA32F running mean),
 // cache (primary hit: bits(tri), u, v, -), shift (2 bytes).
+// Scene triangles are repacked at upload from the 100-byte Triangle (src/Util/Shape.hpp:70-74) to 112 bytes =
+// 7 x float4: [p0 p1 p2 n0 n1 n2 | matid | pad] (5 x 16 B, always read) + [tc0 tc1 tc2 | pad] (2 x 16 B, textured only).
 #pragma once
 #include "canon_math.hpp"
 
@@ -24,13 +31,9 @@ constexpr int kBlockPixels = kBlockDim * kBlockDim;
 constexpr int kTraceThreads = 256;             // 4 waves per workgroup
 constexpr int kLdsStackMax = 8;                // stack entries kept in LDS per lane; deeper entries spill to HBM
 constexpr int kNumSegments = 8;                // one ray-queue segment per XCD
-constexpr int kCursorStride = 32;              // uint32 words between segment cursors: one 128-byte line each (separate L2 channels)
-
-struct DeviceCounters {                        // zeroed at the start of every frame / batch
-	uint32_t queue_count[2];                   // live rays in queue A / B
-	uint32_t cursor[2][kNumSegments];          // persistent-fetch cursors per queue parity
-	uint32_t pad[14];
-};
+constexpr int kCursorStride = 32;              // uint32 words between per-segment counters: one 128-byte line each
+constexpr int kShadeThreads = 256;             // workgroup of the gen / shade / viewer kernels = one queue chunk
+constexpr int kTriFloat4 = 7;                  // device triangle record: 7 x float4
 
 struct DeviceStats {                           // accumulated until adypt_reset_stats
 	unsigned long long rays, nodes, tris, hits, shaded, overflows, bad_materials;
@@ -46,238 +49,13 @@ struct TraceArgs {
 	const float4 *ray_o, *ray_d;
 	float4 *hit;
 	RayStats *ray_stats;           // STATS only (may be null)
-	const uint32_t *count;         // number of rays in the queue (device memory)
-	uint32_t *cursor;              // kNumSegments cursors, zero at launch
+	const uint32_t *count;         // rays per segment: count[s * kCursorStride] (device memory)
+	uint32_t *cursor;              // fetch cursor per segment: cursor[s * kCursorStride], zero at launch
 	uint2 *spill;                  // [(stack_size - lds_depth)][total lanes]
 	DeviceStats *stats;
+	uint32_t seg_cap;              // slots per segment
 	int32_t stack_size, lds_depth;
 };
-
-// ---------------------------------------------------------------------------------------------------------------
-// persistent ray fetch: the queue is cut into kNumSegments contiguous segments (multiples of 64 rays); a workgroup
-// first drains the segment of "its" XCD (workgroups are dealt round-robin over the 8 XCDs, so blockIdx & 7 groups
-// the workgroups that share an L2 — a speed hint only, never needed for correctness), then steals from the others.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool fetch_batch(uint32_t *cursor, uint32_t count, uint32_t seg_size, int home, uint32_t *begin, uint32_t *end)
-{
-	for(int k = 0; k < kNumSegments; ++k)
-	{
-		const int s = (home + k) & (kNumSegments - 1);
-		const uint32_t seg_begin = min((uint32_t)s * seg_size, count);
-		const uint32_t seg_end = min(seg_begin + seg_size, count);
-		if(seg_begin >= seg_end) continue;
-		// cheap pre-check keeps exhausted segments from being hammered with atomics
-		if(__hip_atomic_load(&cursor[s * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seg_end - seg_begin) continue;
-		const uint32_t rel = atomicAdd(&cursor[s * kCursorStride], 64u);
-		if(rel < seg_end - seg_begin)
-		{
-			*begin = seg_begin + rel;
-			*end = min(seg_begin + rel + 64u, seg_end);
-			return true;
-		}
-	}
-	return false;
-}
-
-template <bool STATS>
-__global__ __launch_bounds__(kTraceThreads) void k_trace_v1(TraceArgs a)
-{
-	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64]
-	const int lane = threadIdx.x & 63;
-	const int wave = threadIdx.x >> 6;
-	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
-	const uint32_t total_lanes = gridDim.x * blockDim.x;
-	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
-
-	const uint32_t count = *a.count;
-	const uint32_t seg_size = (((count + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
-	const int home = blockIdx.x & (kNumSegments - 1);
-
-	if(blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats->rays, (unsigned long long)count);
-
-	unsigned long long st_nodes = 0, st_tris = 0, st_hits = 0;
-	uint32_t st_maxdepth = 0;
-	bool any_overflow = false;
-
-	for(;;)
-	{
-		uint32_t b = 0, e = 0;
-		int got = 0;
-		if(lane == 0) got = fetch_batch(a.cursor, count, seg_size, home, &b, &e) ? 1 : 0;
-		got = __builtin_amdgcn_readfirstlane(got);
-		if(!got) break;
-		b = __builtin_amdgcn_readfirstlane(b);
-		e = __builtin_amdgcn_readfirstlane(e);
-		const uint32_t ray = b + lane;
-		if(ray >= e) continue;
-
-		// ---- ray setup (traversal.glsl:16-29) ----
-		const float4 ro = a.ray_o[ray];
-		const float4 rd = a.ray_d[ray];
-		const float ooeps = __uint_as_float((127u - 64u) << 23);
-		F3 dir = f3(rd.x, rd.y, rd.z);
-		dir.x = fabsf(dir.x) > ooeps ? dir.x : (dir.x >= 0 ? ooeps : -ooeps);
-		dir.y = fabsf(dir.y) > ooeps ? dir.y : (dir.y >= 0 ? ooeps : -ooeps);
-		dir.z = fabsf(dir.z) > ooeps ? dir.z : (dir.z >= 0 ? ooeps : -ooeps);
-		dir = normalize3(dir);
-		const F3 idir = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-		const bool nx = dir.x < 0, ny = dir.y < 0, nz = dir.z < 0;
-		const uint32_t octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
-		const uint32_t octinv4 = octinv * 0x01010101u;
-		const F3 origin = f3(ro.x, ro.y, ro.z);
-		const float tmin = ro.w;
-		float hit_t = 1e9f, hit_u = 0.0f, hit_v = 0.0f;
-		int32_t hit_idx = -1;
-
-		int sp = 0;
-		uint32_t ng_x = 0, ng_y = 0x80000000u, tg_x = 0, tg_y = 0;
-		uint32_t n_nodes = 0, n_tris = 0, hash = 0x811c9dc5u, max_depth = 0;
-		bool overflow = false;
-
-		for(;;)
-		{
-			if(ng_y > 0x00ffffffu)
-			{
-				const uint32_t imask = ng_y;
-				const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng_y);
-				const uint32_t base = ng_x;
-				ng_y &= ~(1u << bit);
-				if(ng_y > 0x00ffffffu)
-				{
-					if(sp < a.stack_size)
-					{
-						if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);
-						else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);
-						++sp;
-						if(STATS) max_depth = max(max_depth, (uint32_t)sp);
-					}
-					else overflow = true;
-				}
-				const uint32_t slot = (bit - 24u) ^ octinv;
-				const uint32_t rel = (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
-				const uint32_t node = base + rel;
-
-				const uint4 *np = a.nodes + (size_t)node * 5;
-				const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-				if(STATS) { ++n_nodes; hash = (hash * 0x01000193u) ^ node; }
-
-				const uint32_t head_w = n0.w;
-				const float aix = __uint_as_float((head_w & 0xffu) << 23) * idir.x;
-				const float aiy = __uint_as_float(((head_w >> 8) & 0xffu) << 23) * idir.y;
-				const float aiz = __uint_as_float(((head_w >> 16) & 0xffu) << 23) * idir.z;
-				const float aox = (__uint_as_float(n0.x) - origin.x) * idir.x;
-				const float aoy = (__uint_as_float(n0.y) - origin.y) * idir.y;
-				const float aoz = (__uint_as_float(n0.z) - origin.z) * idir.z;
-
-				ng_x = n1.x;
-				tg_x = n1.y;
-				uint32_t hitmask = 0;
-#pragma unroll
-				for(int g = 0; g < 2; ++g)
-				{
-					const uint32_t meta4 = g ? n1.w : n1.z;
-					const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-					const uint32_t bit_index4 = (meta4 ^ (octinv4 & ((is_inner4 >> 4) * 0xffu))) & 0x1f1f1f1fu;
-					const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
-					const uint32_t qlox = g ? n2.y : n2.x, qloy = g ? n2.w : n2.z, qloz = g ? n3.y : n3.x;
-					const uint32_t qhix = g ? n3.w : n3.z, qhiy = g ? n4.y : n4.x, qhiz = g ? n4.w : n4.z;
-					const uint32_t slox = nx ? qhix : qlox, shix = nx ? qlox : qhix;
-					const uint32_t sloy = ny ? qhiy : qloy, shiy = ny ? qloy : qhiy;
-					const uint32_t sloz = nz ? qhiz : qloz, shiz = nz ? qloz : qhiz;
-#pragma unroll
-					for(int j = 0; j < 4; ++j)
-					{
-						const int sh = 8 * j;
-						const float txmin = fmaf((float)((slox >> sh) & 0xffu), aix, aox);
-						const float tymin = fmaf((float)((sloy >> sh) & 0xffu), aiy, aoy);
-						const float tzmin = fmaf((float)((sloz >> sh) & 0xffu), aiz, aoz);
-						const float txmax = fmaf((float)((shix >> sh) & 0xffu), aix, aox);
-						const float tymax = fmaf((float)((shiy >> sh) & 0xffu), aiy, aoy);
-						const float tzmax = fmaf((float)((shiz >> sh) & 0xffu), aiz, aoz);
-						// no NaN can reach these (finite node data, |idir| <= 2^64): hardware max/min == GLSL max/min
-						const float cmin = fmaxf(fmaxf(txmin, tymin), fmaxf(tzmin, tmin));
-						const float cmax = fminf(fminf(txmax, tymax), fminf(tzmax, hit_t));
-						if(cmin <= cmax) hitmask |= ((child_bits4 >> sh) & 0xffu) << ((bit_index4 >> sh) & 0xffu);
-					}
-				}
-				ng_y = (hitmask & 0xff000000u) | (head_w >> 24);
-				tg_y = hitmask & 0x00ffffffu;
-			}
-			else
-			{
-				tg_x = ng_x; tg_y = ng_y;
-				ng_x = 0; ng_y = 0;
-			}
-
-			while(tg_y != 0)
-			{
-				const uint32_t tb = (uint32_t)__builtin_ctz(tg_y);
-				tg_y &= ~(1u << tb);
-				const uint32_t tri = tg_x + tb;
-				const float4 *wp = a.woop + (size_t)tri * 3;
-				const float4 m0 = wp[0], m1 = wp[1], m2 = wp[2];
-				if(STATS) ++n_tris;
-				const float toz = m0.w - dot3(origin, f3(m0.x, m0.y, m0.z));
-				const float tidz = 1.0f / dot3(dir, f3(m0.x, m0.y, m0.z));
-				const float tt = toz * tidz;
-				const float tox = m1.w + dot3(origin, f3(m1.x, m1.y, m1.z));
-				const float tdx = dot3(dir, f3(m1.x, m1.y, m1.z));
-				const float tu = fmaf(tt, tdx, tox);
-				const float toy = m2.w + dot3(origin, f3(m2.x, m2.y, m2.z));
-				const float tdy = dot3(dir, f3(m2.x, m2.y, m2.z));
-				const float tv = fmaf(tt, tdy, toy);
-				if(tt > tmin && tt < hit_t && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f)
-				{
-					hit_t = tt; hit_u = tu; hit_v = tv; hit_idx = (int32_t)tri;
-				}
-			}
-
-			if(ng_y <= 0x00ffffffu)
-			{
-				if(sp == 0) break;
-				--sp;
-				const uint2 g = sp < a.lds_depth ? my_stack[sp * 64] : my_spill[(size_t)(sp - a.lds_depth) * total_lanes];
-				ng_x = g.x; ng_y = g.y;
-			}
-		}
-
-		const int32_t tri_id = hit_idx != -1 ? a.tri_indices[hit_idx] : -1;
-		a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
-		any_overflow |= overflow;
-		if(STATS)
-		{
-			if(a.ray_stats)
-			{
-				RayStats rs;
-				rs.ref_idx = hit_idx; rs.nodes = n_nodes; rs.tris = n_tris; rs.hash = hash;
-				rs.max_depth = overflow ? 0xffffffffu : max_depth; rs.pad0 = rs.pad1 = rs.pad2 = 0;
-				a.ray_stats[ray] = rs;
-			}
-			st_nodes += n_nodes; st_tris += n_tris; st_hits += hit_idx != -1 ? 1 : 0;
-			st_maxdepth = max(st_maxdepth, max_depth);
-		}
-	}
-
-	if(any_overflow) atomicAdd(&a.stats->overflows, 1ull);
-	if(STATS)
-	{
-		// wave reduction, then one atomic per wave
-		for(int off = 32; off > 0; off >>= 1)
-		{
-			st_nodes += __shfl_down(st_nodes, off);
-			st_tris += __shfl_down(st_tris, off);
-			st_hits += __shfl_down(st_hits, off);
-			st_maxdepth = max(st_maxdepth, (uint32_t)__shfl_down((int)st_maxdepth, off));
-		}
-		if(lane == 0)
-		{
-			atomicAdd(&a.stats->nodes, st_nodes);
-			atomicAdd(&a.stats->tris, st_tris);
-			atomicAdd(&a.stats->hits, st_hits);
-			atomicMax(&a.stats->max_stack, st_maxdepth);
-		}
-	}
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // frame-level parameters (uuCamera + uuPT UBOs of the reference, plus shard geometry)
@@ -296,7 +74,7 @@ struct FrameArgs {
 };
 
 struct SceneArgs {
-	const float *triangles;        // 25 floats per triangle
+	const float4 *triangles;       // kTriFloat4 float4 per triangle (repacked, see header)
 	const float4 *materials;       // 4 x float4 per material
 	const uint32_t *texels;        // RGBA8, all textures back to back
 	const int4 *tex_desc;          // (offset, w, h, 0) per texture
@@ -307,8 +85,9 @@ struct QueueArgs {
 	float4 *ray_o, *ray_d, *col, *rad;   // queue being read (shade) / written (gen)
 	float4 *hit;
 	float4 *out_o, *out_d, *out_col, *out_rad;
-	const uint32_t *count_in;
-	uint32_t *count_out;
+	const uint32_t *count_in;      // [s * kCursorStride]
+	uint32_t *count_out;           // [s * kCursorStride]
+	uint32_t seg_cap;
 };
 
 struct PixelArgs {
@@ -346,37 +125,26 @@ __device__ __forceinline__ F3 camera_dir(const FrameArgs &f, int px, int py, flo
 	return normalize3(r);
 }
 
-constexpr int kShadeThreads = 1024;            // 16 waves per workgroup: one queue-tail atomic per 1024 paths
-
-// workgroup-level stream compaction: returns this thread's output slot (valid only if `alive`).
-// One device atomic per workgroup — a single queue-tail word saturates at ~88 atomics/us (MI355X_MICROARCH price
-// list, "dequeue"), so a per-wave atomic (32 k per 2 M-path launch) alone would cost ~0.37 ms per kernel.
-__device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t *counter)
+// Workgroup-level stream compaction into the workgroup's queue segment: returns this thread's output slot (valid
+// only if `alive`).  Wave vote (__ballot / __popcll) -> scan of the 4 wave counts -> ONE device atomic per workgroup.
+__device__ __forceinline__ uint32_t append_slot(bool alive, uint32_t *seg_counter, uint32_t seg_base)
 {
 	__shared__ uint32_t wave_base[kShadeThreads / 64];
 	const unsigned long long mask = __ballot(alive);
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	if(lane == 0) wave_base[wave] = (uint32_t)__popcll(mask);
 	__syncthreads();
-	if(threadIdx.x < 64)
+	if(threadIdx.x == 0)
 	{
-		const int nw = blockDim.x >> 6;
-		const uint32_t cnt = lane < nw ? wave_base[lane] : 0u;
-		// inclusive scan over (at most 16) wave counts within the first wave
-		uint32_t incl = cnt;
-		for(int off = 1; off < 16; off <<= 1)
-		{
-			const uint32_t up = __shfl_up(incl, off);
-			if(lane >= off) incl += up;
-		}
-		const uint32_t total = __shfl(incl, nw - 1);
-		uint32_t base = 0;
-		if(lane == 0 && total != 0) base = atomicAdd(counter, total);
-		base = __shfl(base, 0);
-		if(lane < nw) wave_base[lane] = base + incl - cnt;
+		uint32_t c[kShadeThreads / 64], total = 0;
+#pragma unroll
+		for(int w = 0; w < kShadeThreads / 64; ++w) { c[w] = wave_base[w]; total += c[w]; }
+		uint32_t base = total ? atomicAdd(seg_counter, total) : 0u;
+#pragma unroll
+		for(int w = 0; w < kShadeThreads / 64; ++w) { wave_base[w] = base; base += c[w]; }
 	}
 	__syncthreads();
-	return wave_base[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+	return seg_base + wave_base[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
 // use_cache: the frame reuses the cached primary hit (spp % tmpLife != 0, pathtracer.glsl:115-120) — the hit
@@ -384,9 +152,12 @@ __device__ __forceinline__ uint32_t compact_slot(bool alive, uint32_t *counter)
 // bias_mode 0: Camera() of primaryray.glsl (no sub-pixel bias); 1: Camera(SubPixel()) of pathtracer.glsl
 __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int use_cache, int bias_mode)
 {
-	const int L = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
+	// each segment takes a contiguous run of local pixels (= whole 32x32 blocks of the image): XCD-local coherence
+	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
+	const int L = (int)(seg * q.seg_cap + local);
 	int x = 0, y = 0;
-	const bool alive = L < f.n_local_px && local_pixel_xy(f, sc.local_blocks, L, &x, &y);
+	const bool alive = local < q.seg_cap && L < f.n_local_px && local_pixel_xy(f, sc.local_blocks, L, &x, &y);
 	float bx = 0.0f, by = 0.0f;
 	if(bias_mode)
 	{
@@ -395,7 +166,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, Scen
 		bx = (float)(sub_idx / f.subpixel) * unit;
 		by = (float)(sub_idx % f.subpixel) * unit;
 	}
-	const uint32_t slot = compact_slot(alive, q.count_out);
+	const uint32_t slot = append_slot(alive, q.count_out + seg * kCursorStride, seg * q.seg_cap);
 	if(!alive) return;
 	const F3 d = camera_dir(f, x, y, bx, by);
 	q.out_o[slot] = make_float4(f.origin[0], f.origin[1], f.origin[2], f.tmin);
@@ -431,12 +202,32 @@ __device__ inline F3 sample_texture(const SceneArgs &sc, int tex, float s, float
 	return r;
 }
 
+// the always-needed 80 bytes of a triangle: positions, normals, material id
+struct TriCore { float v[20]; };
+__device__ __forceinline__ TriCore load_tri_core(const SceneArgs &sc, int tri_idx)
+{
+	const float4 *p = sc.triangles + (size_t)tri_idx * kTriFloat4;
+	const float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+	TriCore t;
+	t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w; t.v[4] = b.x; t.v[5] = b.y; t.v[6] = b.z; t.v[7] = b.w;
+	t.v[8] = c.x; t.v[9] = c.y; t.v[10] = c.z; t.v[11] = c.w; t.v[12] = d.x; t.v[13] = d.y; t.v[14] = d.z; t.v[15] = d.w;
+	t.v[16] = e.x; t.v[17] = e.y; t.v[18] = e.z; t.v[19] = e.w;
+	return t;
+}
 __device__ __forceinline__ F3 bary3(const float *a, const float *b, const float *c, float u, float v, float w)
 {
 	F3 r = f3(a[0], a[1], a[2]) * u;
 	r = fma3(f3(b[0], b[1], b[2]), v, r);
 	r = fma3(f3(c[0], c[1], c[2]), w, r);
 	return r;
+}
+__device__ __forceinline__ F3 textured_diffuse(const SceneArgs &sc, int tri_idx, int dtex, float u, float v, float w)
+{
+	const float4 *p = sc.triangles + (size_t)tri_idx * kTriFloat4 + 5;
+	const float4 a = p[0], b = p[1]; // tc0.xy tc1.xy | tc2.xy pad
+	const float ts = fmaf(b.x, w, fmaf(a.z, v, a.x * u));
+	const float tt = fmaf(b.y, w, fmaf(a.w, v, a.y * u));
+	return sample_texture(sc, dtex, ts, tt);
 }
 
 struct Rng { float sx, sy; const float *sobol; };
@@ -478,9 +269,12 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 // store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
 __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int b, int store_cache)
 {
-	const uint32_t n_in = *q.count_in;
-	const uint32_t slot_in = blockIdx.x * blockDim.x + threadIdx.x;
-	bool alive = slot_in < n_in;
+	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
+	const uint32_t n_in = q.count_in[seg * kCursorStride];
+	if(chunk * kShadeThreads >= n_in) return; // whole workgroup beyond the segment's live range (uniform exit)
+	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
+	const uint32_t slot_in = seg * q.seg_cap + local;
+	bool alive = local < n_in;
 	F3 origin = f3(0, 0, 0), dir = f3(0, 0, 1), color = f3(0, 0, 0), ret = f3(0, 0, 0);
 	int L = 0;
 	bool shaded = false, bad_mat = false;
@@ -502,8 +296,9 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 		}
 		else
 		{
-			const float *tri = sc.triangles + (size_t)tri_idx * 25;
-			const int matid = __float_as_int(tri[24]);
+			const TriCore tc = load_tri_core(sc, tri_idx);
+			const float *tri = tc.v;
+			const int matid = __float_as_int(tri[18]);
 			if(matid < 0 || matid >= f.n_mats) { alive = false; bad_mat = true; }
 			else
 			{
@@ -516,12 +311,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 				F3 normal = normalize3(bary3(tri + 9, tri + 12, tri + 15, tu, tv, w));
 				origin = bary3(tri + 0, tri + 3, tri + 6, tu, tv, w);
 				F3 diffuse;
-				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex)
-				{
-					const float ts = fmaf(tri[22], w, fmaf(tri[20], tv, tri[18] * tu));
-					const float tt = fmaf(tri[23], w, fmaf(tri[21], tv, tri[19] * tu));
-					diffuse = sample_texture(sc, dtex, ts, tt);
-				}
+				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) diffuse = textured_diffuse(sc, tri_idx, dtex, tu, tv, w);
 				else diffuse = f3(md.y, md.z, md.w);
 				const F3 specular = f3(ms.y, ms.z, ms.w);
 				ret = fma3(color, f3(me.y, me.z, me.w), ret);
@@ -602,7 +392,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 			if(mb) atomicAdd(&px.stats->bad_materials, (unsigned long long)__popcll(mb));
 		}
 	}
-	const uint32_t slot = compact_slot(alive, q.count_out);
+	const uint32_t slot = append_slot(alive, q.count_out + seg * kCursorStride, seg * q.seg_cap);
 	if(alive)
 	{
 		q.out_o[slot] = make_float4(origin.x, origin.y, origin.z, f.tmin);
@@ -613,11 +403,13 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 }
 
 // primaryray.glsl main (:46-94): colour the primary hit by viewer type; also records the hit in the cache image
-__global__ __launch_bounds__(256) void k_viewer(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int viewer_type)
+__global__ __launch_bounds__(kShadeThreads) void k_viewer(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int viewer_type)
 {
-	const uint32_t n_in = *q.count_in;
-	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-	if(slot >= n_in) return;
+	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
+	const uint32_t n_in = q.count_in[seg * kCursorStride];
+	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
+	if(local >= n_in) return;
+	const uint32_t slot = seg * q.seg_cap + local;
 	const float4 rd = q.ray_d[slot], h = q.hit[slot];
 	const int L = __float_as_int(rd.w);
 	const int tri_idx = __float_as_int(h.x);
@@ -626,8 +418,9 @@ __global__ __launch_bounds__(256) void k_viewer(FrameArgs f, SceneArgs sc, Queue
 	F3 color = f3(0, 0, 0);
 	if(tri_idx != -1)
 	{
-		const float *tri = sc.triangles + (size_t)tri_idx * 25;
-		const int matid = __float_as_int(tri[24]);
+		const TriCore tc = load_tri_core(sc, tri_idx);
+		const float *tri = tc.v;
+		const int matid = __float_as_int(tri[18]);
 		if(matid >= 0 && matid < f.n_mats)
 		{
 			const float4 *mp = sc.materials + (size_t)matid * 4;
@@ -636,12 +429,7 @@ __global__ __launch_bounds__(256) void k_viewer(FrameArgs f, SceneArgs sc, Queue
 			const float w = 1.0f - u - v;
 			if(viewer_type == 0)
 			{
-				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex)
-				{
-					const float ts = fmaf(tri[22], w, fmaf(tri[20], v, tri[18] * u));
-					const float tt = fmaf(tri[23], w, fmaf(tri[21], v, tri[19] * u));
-					color = sample_texture(sc, dtex, ts, tt);
-				}
+				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) color = textured_diffuse(sc, tri_idx, dtex, u, v, w);
 				else color = f3(md.y, md.z, md.w);
 			}
 			else if(viewer_type == 1) color = f3(ms.y, ms.z, ms.w);

@@ -5,7 +5,7 @@
 //     memset counters -> k_gen_primary -> [ k_trace -> k_shade ] x maxBounce      (all on ctx->stream, no host sync;
 //     queue sizes live in device memory, the traversal kernel is persistent, the shade grid covers the worst case)
 // There is no CPU fallback anywhere in this file: without a HIP device adypt_create fails with ADYPT_E_NO_DEVICE.
-#include "trace.hpp"
+#include "traverse.hpp"
 #include "../../../include/adypt_hip.h"
 #include "../../../include/adypt_host.h"
 
@@ -22,9 +22,9 @@ namespace {
 
 constexpr int kMaxBounce = 32;
 
-struct FrameCounters {                 // one memset per frame
-	uint32_t count[kMaxBounce + 1];
-	uint32_t cursor[kMaxBounce + 1][kNumSegments * kCursorStride];
+struct FrameCounters {                 // one memset per frame; every counter on its own 128-byte line
+	uint32_t count[kMaxBounce + 1][kNumSegments * kCursorStride];   // live rays per queue segment after bounce b
+	uint32_t cursor[kMaxBounce + 1][kNumSegments * kCursorStride];  // traversal fetch cursors per segment
 };
 
 thread_local std::string g_create_error;
@@ -52,7 +52,8 @@ struct adypt_ctx {
 	uint8_t *d_shift = nullptr;
 
 	// wavefront queues
-	int64_t capacity = 0;
+	int64_t capacity = 0;      // queue slots = kNumSegments * seg_cap
+	uint32_t seg_cap = 0;      // slots per XCD-affine segment (multiple of kShadeThreads)
 	float4 *q_o[2] = {nullptr, nullptr}, *q_d[2] = {nullptr, nullptr}, *q_col[2] = {nullptr, nullptr}, *q_rad[2] = {nullptr, nullptr};
 	float4 *d_hit = nullptr;
 	RayStats *d_ray_stats = nullptr;
@@ -63,7 +64,6 @@ struct adypt_ctx {
 
 	// launch geometry of the persistent traversal kernel
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0;
-	bool use_v1 = false;
 
 	// state
 	adypt_pt_params params{}, pending{};
@@ -198,8 +198,7 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	c->lds_depth = std::max(1, std::min(stack_size, kLdsStackMax));
 	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	int per_cu = 0;
-	if(c->use_v1) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_v1<false>, kTraceThreads, lds));
-	else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
+	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
 	if(const char *ov = getenv("ADYPT_TRACE_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, atoi(ov)));
 	per_cu = std::max(1, std::min(per_cu, 8));
 	c->trace_blocks = c->num_cus * per_cu;
@@ -218,16 +217,11 @@ int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *curs
 	a.count = count; a.cursor = cursor;
 	a.spill = c->d_spill;
 	a.stats = c->d_stats;
+	a.seg_cap = c->seg_cap;
 	a.stack_size = stack_size; a.lds_depth = c->lds_depth;
 	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	hipEvent_t *stop = begin_timing(c, 0);
-	if(c->use_v1)
-	{
-		// batch-synchronous first version, kept for A/B measurements (ADYPT_TRACE_V1=1)
-		if(stats) hipLaunchKernelGGL(k_trace_v1<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
-		else hipLaunchKernelGGL(k_trace_v1<false>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
-	}
-	else if(stats) hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
+	if(stats) hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
 	else hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
 	end_timing(c, stop);
 	HIP_TRY(c, hipGetLastError());
@@ -249,7 +243,7 @@ void fill_frame(const adypt_ctx *c, FrameArgs *f)
 }
 void fill_scene(const adypt_ctx *c, SceneArgs *s)
 {
-	s->triangles = (const float *)c->d_triangles;
+	s->triangles = (const float4 *)c->d_triangles;
 	s->materials = (const float4 *)c->d_materials;
 	s->texels = (const uint32_t *)c->d_texels;
 	s->tex_desc = (const int4 *)c->d_tex_desc;
@@ -266,6 +260,7 @@ QueueArgs queue_args(adypt_ctx *c, int in, const uint32_t *count_in, uint32_t *c
 	q.hit = c->d_hit;
 	q.out_o = c->q_o[in ^ 1]; q.out_d = c->q_d[in ^ 1]; q.out_col = c->q_col[in ^ 1]; q.out_rad = c->q_rad[in ^ 1];
 	q.count_in = count_in; q.count_out = count_out;
+	q.seg_cap = c->seg_cap;
 	return q;
 }
 
@@ -375,7 +370,6 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	hipDeviceProp_t prop;
 	HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
 	c->num_cus = prop.multiProcessorCount;
-	c->use_v1 = getenv("ADYPT_TRACE_V1") != nullptr;
 
 	c->n_nodes = d->n_nodes; c->n_refs = d->n_refs; c->n_tris = d->n_tris; c->n_mats = d->n_mats; c->n_tex = d->n_textures;
 	c->width = d->width; c->height = d->height; c->rank = d->tile_rank; c->nranks = d->tile_nranks;
@@ -392,7 +386,19 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		if(!wp) { woop.resize((size_t)d->n_refs * 12); adypt_woop_matrices(d->triangles, d->tri_indices, d->n_refs, woop.data()); wp = woop.data(); }
 		TRY_CREATE(upload(c, &c->d_woop, wp, (size_t)d->n_refs * 12));
 	}
-	TRY_CREATE(upload(c, &c->d_triangles, (const uint8_t *)d->triangles, (size_t)d->n_tris * 100));
+	{
+		// 100-byte Triangle -> 112-byte device record (shade.hpp): [p n matid pad] + [tc pad]
+		std::vector<float> packed((size_t)d->n_tris * kTriFloat4 * 4, 0.0f);
+		const uint8_t *src = (const uint8_t *)d->triangles;
+		for(int64_t i = 0; i < d->n_tris; ++i)
+		{
+			float *o = packed.data() + (size_t)i * kTriFloat4 * 4;
+			memcpy(o, src + i * 100, 72);            // positions + normals
+			memcpy(o + 18, src + i * 100 + 96, 4);   // material id
+			memcpy(o + 20, src + i * 100 + 72, 24);  // texture coordinates
+		}
+		TRY_CREATE(upload(c, &c->d_triangles, packed.data(), packed.size()));
+	}
 	TRY_CREATE(upload(c, &c->d_materials, (const uint8_t *)d->materials, (size_t)d->n_mats * 64));
 	{
 		std::vector<uint32_t> texels;
@@ -419,15 +425,20 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	HIP_CREATE(hipMemset(c->d_accum, 0, npx * sizeof(float4)));
 	HIP_CREATE(hipMemset(c->d_cache, 0xff, npx * sizeof(float4)));
 	HIP_CREATE(hipMemset(c->d_shift, 0, npx * 2));
-	c->capacity = (int64_t)npx;
+	{
+		const size_t chunks = (npx + kShadeThreads - 1) / kShadeThreads;
+		c->seg_cap = (uint32_t)(((chunks + kNumSegments - 1) / kNumSegments) * kShadeThreads);
+		c->capacity = (int64_t)c->seg_cap * kNumSegments;
+	}
+	const size_t nq = (size_t)c->capacity;
 	for(int i = 0; i < 2; ++i)
 	{
-		HIP_CREATE(hipMalloc((void **)&c->q_o[i], npx * sizeof(float4)));
-		HIP_CREATE(hipMalloc((void **)&c->q_d[i], npx * sizeof(float4)));
-		HIP_CREATE(hipMalloc((void **)&c->q_col[i], npx * sizeof(float4)));
-		HIP_CREATE(hipMalloc((void **)&c->q_rad[i], npx * sizeof(float4)));
+		HIP_CREATE(hipMalloc((void **)&c->q_o[i], nq * sizeof(float4)));
+		HIP_CREATE(hipMalloc((void **)&c->q_d[i], nq * sizeof(float4)));
+		HIP_CREATE(hipMalloc((void **)&c->q_col[i], nq * sizeof(float4)));
+		HIP_CREATE(hipMalloc((void **)&c->q_rad[i], nq * sizeof(float4)));
 	}
-	HIP_CREATE(hipMalloc((void **)&c->d_hit, npx * sizeof(float4)));
+	HIP_CREATE(hipMalloc((void **)&c->d_hit, nq * sizeof(float4)));
 	HIP_CREATE(hipMalloc((void **)&c->d_counters, sizeof(FrameCounters)));
 	HIP_CREATE(hipMalloc((void **)&c->d_stats, sizeof(DeviceStats)));
 	HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(FrameCounters)));
@@ -513,19 +524,19 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	FrameArgs f; SceneArgs sc; PixelArgs px;
 	fill_frame(c, &f); fill_scene(c, &sc); fill_pixels(c, &px);
 	HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
-	const int grid = (c->n_local_px + 255) / 256, grid_c = (c->n_local_px + kShadeThreads - 1) / kShadeThreads;
+	const int grid_c = (int)(c->capacity / kShadeThreads); // kNumSegments x chunks per segment
 	{
-		QueueArgs q = queue_args(c, 1, &c->d_counters->count[0], &c->d_counters->count[0]); // writes queue 0
+		QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0]); // writes queue 0
 		hipEvent_t *stop = begin_timing(c, 1);
 		hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 0);
 		end_timing(c, stop);
 	}
-	r = launch_trace(c, 0, &c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr);
+	r = launch_trace(c, 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr);
 	if(r != ADYPT_OK) return r;
 	{
-		QueueArgs q = queue_args(c, 0, &c->d_counters->count[0], &c->d_counters->count[1]);
+		QueueArgs q = queue_args(c, 0, c->d_counters->count[0], c->d_counters->count[1]);
 		hipEvent_t *stop = begin_timing(c, 1);
-		hipLaunchKernelGGL(k_viewer, dim3(grid), dim3(256), 0, c->stream, f, sc, q, px, viewer_type);
+		hipLaunchKernelGGL(k_viewer, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, viewer_type);
 		end_timing(c, stop);
 	}
 	HIP_TRY(c, hipGetLastError());
@@ -541,7 +552,7 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 	HIP_TRY(c, hipSetDevice(c->device));
 	SceneArgs sc; PixelArgs px;
 	fill_scene(c, &sc); fill_pixels(c, &px);
-	const int grid = (c->n_local_px + 255) / 256, grid_c = (c->n_local_px + kShadeThreads - 1) / kShadeThreads;
+	const int grid_c = (int)(c->capacity / kShadeThreads); // kNumSegments x chunks per segment
 	const bool stats = (c->instrumentation & 2) != 0;
 	for(int s = 0; s < n_spp; ++s)
 	{
@@ -567,7 +578,7 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 		const int use_cache = (c->spp % c->params.tmp_lifetime) != 0;
 		HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
 		{
-			QueueArgs q = queue_args(c, 1, &c->d_counters->count[0], &c->d_counters->count[0]); // out = queue 0
+			QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0]); // out = queue 0
 			hipEvent_t *stop = begin_timing(c, 1);
 			hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, use_cache, 1);
 			end_timing(c, stop);
@@ -577,10 +588,10 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 			const int in = b & 1;
 			if(!(b == 0 && use_cache))
 			{
-				int r = launch_trace(c, in, &c->d_counters->count[b], c->d_counters->cursor[b], c->params.stack_size, stats, nullptr);
+				int r = launch_trace(c, in, c->d_counters->count[b], c->d_counters->cursor[b], c->params.stack_size, stats, nullptr);
 				if(r != ADYPT_OK) return r;
 			}
-			QueueArgs q = queue_args(c, in, &c->d_counters->count[b], &c->d_counters->count[b + 1]);
+			QueueArgs q = queue_args(c, in, c->d_counters->count[b], c->d_counters->count[b + 1]);
 			hipEvent_t *stop = begin_timing(c, 1);
 			hipLaunchKernelGGL(k_shade, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, b, (b == 0 && !use_cache) ? 1 : 0);
 			end_timing(c, stop);
@@ -639,18 +650,30 @@ int adypt_trace_rays(adypt_ctx *c, const float *rays, int64_t n, adypt_hit *hits
 			o[(size_t)i] = make_float4(r[0], r[1], r[2], r[3]);
 			d[(size_t)i] = make_float4(r[4], r[5], r[6], 0.0f);
 		}
+		// the batch is cut into kNumSegments consecutive pieces, piece s occupying the head of queue segment s
 		HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
-		HIP_TRY(c, hipMemcpyAsync(c->q_o[0], o.data(), (size_t)m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-		HIP_TRY(c, hipMemcpyAsync(c->q_d[0], d.data(), (size_t)m * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-		const uint32_t cnt = (uint32_t)m;
-		HIP_TRY(c, hipMemcpyAsync(&c->d_counters->count[0], &cnt, 4, hipMemcpyHostToDevice, c->stream));
-		int r = launch_trace(c, 0, &c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, with_stats != 0, with_stats ? c->d_ray_stats : nullptr);
-		if(r != ADYPT_OK) return r;
-		HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_hit, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-		if(with_stats)
+		const int64_t piece = (m + kNumSegments - 1) / kNumSegments; // <= seg_cap because m <= capacity
+		uint32_t counts[kNumSegments * kCursorStride] = {0};
+		if(with_stats) rs.resize((size_t)m);
+		for(int s = 0; s < kNumSegments; ++s)
 		{
-			rs.resize((size_t)m);
-			HIP_TRY(c, hipMemcpyAsync(rs.data(), c->d_ray_stats, (size_t)m * sizeof(RayStats), hipMemcpyDeviceToHost, c->stream));
+			const int64_t b0 = std::min<int64_t>(piece * s, m), n_s = std::min<int64_t>(piece, m - b0);
+			counts[s * kCursorStride] = (uint32_t)n_s;
+			if(n_s <= 0) continue;
+			const size_t off = (size_t)s * c->seg_cap;
+			HIP_TRY(c, hipMemcpyAsync(c->q_o[0] + off, o.data() + b0, (size_t)n_s * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+			HIP_TRY(c, hipMemcpyAsync(c->q_d[0] + off, d.data() + b0, (size_t)n_s * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+		}
+		HIP_TRY(c, hipMemcpyAsync(c->d_counters->count[0], counts, sizeof(counts), hipMemcpyHostToDevice, c->stream));
+		int r = launch_trace(c, 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, with_stats != 0, with_stats ? c->d_ray_stats : nullptr);
+		if(r != ADYPT_OK) return r;
+		for(int s = 0; s < kNumSegments; ++s)
+		{
+			const int64_t b0 = std::min<int64_t>(piece * s, m), n_s = std::min<int64_t>(piece, m - b0);
+			if(n_s <= 0) continue;
+			const size_t off = (size_t)s * c->seg_cap;
+			HIP_TRY(c, hipMemcpyAsync(h.data() + b0, c->d_hit + off, (size_t)n_s * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+			if(with_stats) HIP_TRY(c, hipMemcpyAsync(rs.data() + b0, c->d_ray_stats + off, (size_t)n_s * sizeof(RayStats), hipMemcpyDeviceToHost, c->stream));
 		}
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		for(int64_t i = 0; i < m; ++i)

@@ -3,42 +3,41 @@
 // Semantics: exactly BVHIntersection of shaders/traversal.glsl:14-255 — same node-visit order, same triangle test
 // order, same arithmetic (canon_math.hpp) — so hit ids, u/v/t bits and the visit hash equal the oracle's.
 // What is re-designed for the machine (none of it changes a result):
-//   * persistent waves with per-lane ray replacement: a lane whose ray has finished is refilled from the ray queue
-//     as soon as >= kRefillMin lanes of its wave are idle (wave vote with __ballot / __popcll, one queue atomic per
-//     refill), instead of the whole wave waiting for its slowest ray (measured SIMT utilisation of the
-//     batch-synchronous version: 19 %).
+//   * persistent waves with per-lane ray replacement: a lane whose ray has finished is refilled as soon as
+//     >= kRefillMin lanes of its wave are idle (wave vote with __ballot / __popcll), instead of the whole wave
+//     waiting for its slowest ray (measured SIMT utilisation of the batch-synchronous first version: 19 %).
+//     Rays are reserved from the queue kChunk at a time (one device atomic per chunk, wave-private range handed out
+//     to idle lanes without further atomics): a per-refill atomic was measured 2.5x slower end to end.
 //   * software-pipelined node fetch: which node comes next (closest remaining child of the current group, or the
 //     popped group) is decided by the *previous* slab test and does not depend on the triangle tests in between, so
-//     its 5 x 16-byte loads are issued before the triangle tests of the current node and their latencies overlap.
-//     Triangles are fetched two at a time for the same reason.  The slab test itself still runs after the triangle
-//     tests (it needs the shortened hit_t), exactly like the reference.
+//     its 5 x 16-byte loads are issued together with the loads of the first two triangles of the current node and
+//     the latencies overlap.  The slab test itself still runs after the triangle tests (it needs the shortened
+//     hit_t), exactly like the reference.
 //   * the node-group stack lives in LDS, laid out [depth][lane] (ds_write_b64 / ds_read_b64, conflict free); only
 //     entries deeper than kLdsStackMax spill to a global scratch array.  Overflow beyond stackSize is reported.
-//   * XCD-aware queue segments (see fetch_rays).
+//   * XCD-affine queue segments with separate fetch cursors on separate cache lines (see shade.hpp).
 #pragma once
-#include "kernels.hpp"
+#include "shade.hpp"
 
 namespace adypt {
 
 constexpr int kRefillMin = 16; // refill when at least this many lanes of the wave are idle (or all are)
-constexpr int kChunk = 128;    // rays reserved per queue atomic (wave-private range, handed out to idle lanes without atomics)
+constexpr int kChunk = 128;    // rays reserved per queue atomic
 
-// Grab up to `want` consecutive rays.  The queue is cut into kNumSegments contiguous segments; a workgroup first
-// drains the segment of "its" XCD (workgroups are dealt round-robin over the 8 XCDs, so blockIdx & 7 groups the
-// workgroups that share an L2 — a speed hint only), then steals from the other segments.
-__device__ __forceinline__ uint32_t fetch_rays(uint32_t *cursor, uint32_t count, uint32_t seg_size, int home, uint32_t want, uint32_t *begin)
+// Reserve up to `want` consecutive rays: first from the segment of "our" XCD (blockIdx & 7 groups the workgroups
+// that share an L2 under the observed round-robin dispatch — a speed hint only), then steal from the others.
+__device__ __forceinline__ uint32_t fetch_rays(const uint32_t *count, uint32_t *cursor, uint32_t seg_cap, int home, uint32_t want, uint32_t *begin)
 {
 	for(int k = 0; k < kNumSegments; ++k)
 	{
 		const int s = (home + k) & (kNumSegments - 1);
-		const uint32_t seg_begin = min((uint32_t)s * seg_size, count);
-		const uint32_t seg_len = min(seg_begin + seg_size, count) - seg_begin;
+		const uint32_t seg_len = count[s * kCursorStride];
 		if(seg_len == 0) continue;
 		if(__hip_atomic_load(&cursor[s * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seg_len) continue;
 		const uint32_t rel = atomicAdd(&cursor[s * kCursorStride], want);
 		if(rel < seg_len)
 		{
-			*begin = seg_begin + rel;
+			*begin = (uint32_t)s * seg_cap + rel;
 			return min(want, seg_len - rel);
 		}
 	}
@@ -54,11 +53,14 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
 	const uint32_t total_lanes = gridDim.x * blockDim.x;
 	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
-
-	const uint32_t count = *a.count;
-	const uint32_t seg_size = (((count + kNumSegments - 1) / kNumSegments) + 63u) & ~63u;
 	const int home = blockIdx.x & (kNumSegments - 1);
-	if(blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats->rays, (unsigned long long)count);
+
+	if(blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		unsigned long long total = 0;
+		for(int s = 0; s < kNumSegments; ++s) total += a.count[s * kCursorStride];
+		atomicAdd(&a.stats->rays, total);
+	}
 
 	// per-lane ray state
 	bool active = false;
@@ -87,10 +89,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 		{
 			if(loc_next == loc_end)
 			{
-				// reserve the next chunk of the queue for this wave: one device atomic per kChunk rays.  (A per-refill
-				// atomic was measured 2.5x slower end to end: all cursors serialise in the L2 atomic unit.)
 				uint32_t cb = 0, cn = 0;
-				if(lane == 0) cn = fetch_rays(a.cursor, count, seg_size, home, (uint32_t)kChunk, &cb);
+				if(lane == 0) cn = fetch_rays(a.count, a.cursor, a.seg_cap, home, (uint32_t)kChunk, &cb);
 				cn = __builtin_amdgcn_readfirstlane(cn);
 				cb = __builtin_amdgcn_readfirstlane(cb);
 				loc_next = cb; loc_end = cb + cn;
