@@ -267,7 +267,7 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 
 // One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for every live path.
 // store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
-__global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int b, int store_cache)
+__global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int b, int store_cache, int count_stats)
 {
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	const uint32_t n_in = q.count_in[seg * kCursorStride];
@@ -383,13 +383,15 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 		}
 		if(!alive) finish_path(f, px, L, ret);
 	}
-	// statistics: one atomic per wave
+	// statistics.  The FetchInfo count is only collected in instrumented runs: even one atomic per wave on a single
+	// word (23 k per launch) costs ~0.27 ms on this chip (~88 same-address atomics/us) — it was 75 % of this kernel.
 	{
-		const unsigned long long m = __ballot(shaded), mb = __ballot(bad_mat);
-		if((threadIdx.x & 63) == 0)
+		const unsigned long long mb = __ballot(bad_mat);
+		if(mb && (threadIdx.x & 63) == 0) atomicAdd(&px.stats->bad_materials, (unsigned long long)__popcll(mb));
+		if(count_stats)
 		{
-			if(m) atomicAdd(&px.stats->shaded, (unsigned long long)__popcll(m));
-			if(mb) atomicAdd(&px.stats->bad_materials, (unsigned long long)__popcll(mb));
+			const unsigned long long m = __ballot(shaded);
+			if(m && (threadIdx.x & 63) == 0) atomicAdd(&px.stats->shaded, (unsigned long long)__popcll(m));
 		}
 	}
 	const uint32_t slot = append_slot(alive, q.count_out + seg * kCursorStride, seg * q.seg_cap);

@@ -593,7 +593,7 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 			}
 			QueueArgs q = queue_args(c, in, c->d_counters->count[b], c->d_counters->count[b + 1]);
 			hipEvent_t *stop = begin_timing(c, 1);
-			hipLaunchKernelGGL(k_shade, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, b, (b == 0 && !use_cache) ? 1 : 0);
+			hipLaunchKernelGGL(k_shade, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
 			end_timing(c, stop);
 		}
 		HIP_TRY(c, hipGetLastError());
