@@ -55,6 +55,7 @@ struct TraceArgs {
 	DeviceStats *stats;
 	uint32_t seg_cap;              // slots per segment
 	int32_t stack_size, lds_depth;
+	uint32_t refill_min, chunk;    // tunables of the persistent fetch (traverse.hpp)
 };
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -63,7 +63,8 @@ struct adypt_ctx {
 	size_t spill_bytes = 0;
 
 	// launch geometry of the persistent traversal kernel
-	int num_cus = 0, trace_blocks = 0, lds_depth = 0;
+	int num_cus = 0, trace_blocks = 0, lds_depth = 0, occupancy_api = 0;
+	uint32_t refill_min = kRefillMin, chunk = kChunk;
 
 	// state
 	adypt_pt_params params{}, pending{};
@@ -199,8 +200,9 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	int per_cu = 0;
 	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
-	if(const char *ov = getenv("ADYPT_TRACE_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, atoi(ov)));
+	c->occupancy_api = per_cu;
 	per_cu = std::max(1, std::min(per_cu, 8));
+	if(const char *ov = getenv("ADYPT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(16, atoi(ov))); // tuning override
 	c->trace_blocks = c->num_cus * per_cu;
 	return ensure_spill(c, stack_size);
 }
@@ -218,6 +220,7 @@ int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *curs
 	a.spill = c->d_spill;
 	a.stats = c->d_stats;
 	a.seg_cap = c->seg_cap;
+	a.refill_min = c->refill_min; a.chunk = c->chunk;
 	a.stack_size = stack_size; a.lds_depth = c->lds_depth;
 	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	hipEvent_t *stop = begin_timing(c, 0);
@@ -370,6 +373,8 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	hipDeviceProp_t prop;
 	HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
 	c->num_cus = prop.multiProcessorCount;
+	if(const char *ov = getenv("ADYPT_REFILL_MIN")) c->refill_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
+	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
 
 	c->n_nodes = d->n_nodes; c->n_refs = d->n_refs; c->n_tris = d->n_tris; c->n_mats = d->n_mats; c->n_tex = d->n_textures;
 	c->width = d->width; c->height = d->height; c->rank = d->tile_rank; c->nranks = d->tile_nranks;

@@ -21,8 +21,8 @@
 
 namespace adypt {
 
-constexpr int kRefillMin = 16; // refill when at least this many lanes of the wave are idle (or all are)
-constexpr int kChunk = 128;    // rays reserved per queue atomic
+constexpr int kRefillMin = 16; // default: refill when at least this many lanes of the wave are idle (or all are)
+constexpr int kChunk = 128;    // default: rays reserved per queue atomic
 
 // Reserve up to `want` consecutive rays: first from the segment of "our" XCD (blockIdx & 7 groups the workgroups
 // that share an L2 under the observed round-robin dispatch — a speed hint only), then steal from the others.
@@ -85,12 +85,12 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 		// ---------------- refill idle lanes ----------------
 		const unsigned long long idle = __ballot(!active);
 		const uint32_t n_idle = (uint32_t)__popcll(idle);
-		if((!exhausted || loc_next < loc_end) && (n_idle >= (uint32_t)kRefillMin))
+		if((!exhausted || loc_next < loc_end) && (n_idle >= a.refill_min))
 		{
 			if(loc_next == loc_end)
 			{
 				uint32_t cb = 0, cn = 0;
-				if(lane == 0) cn = fetch_rays(a.count, a.cursor, a.seg_cap, home, (uint32_t)kChunk, &cb);
+				if(lane == 0) cn = fetch_rays(a.count, a.cursor, a.seg_cap, home, a.chunk, &cb);
 				cn = __builtin_amdgcn_readfirstlane(cn);
 				cb = __builtin_amdgcn_readfirstlane(cb);
 				loc_next = cb; loc_end = cb + cn;
