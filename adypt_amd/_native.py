@@ -86,6 +86,8 @@ _SIGS = {
     "adypt_trace_spp": (C.c_int, [C.c_void_p, C.c_int]),
     "adypt_reset": (C.c_int, [C.c_void_p]),
     "adypt_get_spp": (C.c_int, [C.c_void_p]),
+    "adypt_set_frames_in_flight": (C.c_int, [C.c_void_p, C.c_int]),
+    "adypt_get_frames_in_flight": (C.c_int, [C.c_void_p]),
     "adypt_read_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adypt_read_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "adypt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),

@@ -329,6 +329,12 @@ class HipPathTracer:
     def GetSPP(self) -> int:
         return N.lib.adypt_get_spp(self._ctx)
 
+    def SetFramesInFlight(self, n: int) -> None:
+        N.check(N.lib.adypt_set_frames_in_flight(self._ctx, n), self._ctx)
+
+    def GetFramesInFlight(self) -> int:
+        return N.lib.adypt_get_frames_in_flight(self._ctx)
+
     def ReadResult(self) -> np.ndarray:
         rgb = np.zeros((self.height, self.width, 3), dtype=np.float32)
         N.check(N.lib.adypt_read_radiance(self._ctx, rgb.ctypes.data), self._ctx)

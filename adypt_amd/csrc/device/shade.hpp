@@ -65,9 +65,11 @@ struct FrameArgs {
 	float inv_proj[16], inv_view[16];
 	float origin[3], tmin;
 	float sun[3], clamp;
-	float sobol[64];               // this frame's Sobol point: 2*max_bounce floats (pathtracer.glsl:46,49)
+	const float *sobol;            // device: [frame in batch][64] — each frame's Sobol point, 2*max_bounce floats used (pathtracer.glsl:46,49)
+	float4 *done;                  // device: [frame in batch][local pixel] finished sample radiance (batches of > 1 frame only)
 	int32_t width, height;
-	int32_t spp, subpixel, tmp_life, max_bounce;
+	int32_t spp, subpixel, tmp_life, max_bounce; // spp = index of the FIRST frame of the batch
+	int32_t n_frames;              // frames in flight in this pass (path index = frame * n_local_px + local pixel)
 	int32_t n_local_px;            // owned blocks * 1024
 	int32_t blocks_x;              // image width in 32-px blocks
 	int32_t rank, nranks;
@@ -156,13 +158,14 @@ __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, Scen
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	// each segment takes a contiguous run of local pixels (= whole 32x32 blocks of the image): XCD-local coherence
 	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
-	const int L = (int)(seg * q.seg_cap + local);
+	const uint32_t pi = seg * q.seg_cap + local; // path index = frame * n_local_px + local pixel
+	const int frame = (int)(pi / (uint32_t)f.n_local_px), L = (int)(pi % (uint32_t)f.n_local_px);
 	int x = 0, y = 0;
-	const bool alive = local < q.seg_cap && L < f.n_local_px && local_pixel_xy(f, sc.local_blocks, L, &x, &y);
+	const bool alive = local < q.seg_cap && frame < f.n_frames && local_pixel_xy(f, sc.local_blocks, L, &x, &y);
 	float bx = 0.0f, by = 0.0f;
 	if(bias_mode)
 	{
-		const int sub_idx = (f.spp / f.tmp_life) % (f.subpixel * f.subpixel);
+		const int sub_idx = ((f.spp + frame) / f.tmp_life) % (f.subpixel * f.subpixel);
 		const float unit = 1.0f / (float)f.subpixel;
 		bx = (float)(sub_idx / f.subpixel) * unit;
 		by = (float)(sub_idx % f.subpixel) * unit;
@@ -171,10 +174,39 @@ __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, Scen
 	if(!alive) return;
 	const F3 d = camera_dir(f, x, y, bx, by);
 	q.out_o[slot] = make_float4(f.origin[0], f.origin[1], f.origin[2], f.tmin);
-	q.out_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(L));
+	q.out_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float((int)pi));
 	q.out_col[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 	q.out_rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	if(use_cache) q.hit[slot] = px.cache[L];
+}
+
+// Batches of several frames: the frame that re-traces its primary rays (spp % tmpLife == 0) runs a primary-only
+// pass first and parks the hits in the cache image (pathtracer.glsl:121-127); every frame of the batch then starts
+// from the cache.
+__global__ __launch_bounds__(kShadeThreads) void k_store_cache(QueueArgs q, PixelArgs px)
+{
+	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
+	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
+	if(local >= q.count_in[seg * kCursorStride]) return;
+	const uint32_t slot = seg * q.seg_cap + local;
+	const float4 h = q.hit[slot];
+	px.cache[__float_as_int(q.ray_d[slot].w)] = make_float4(h.x, h.y, h.z, 0.0f); // primary pass: path index == local pixel
+}
+
+// Applies the finished samples of a batch to the running mean in frame order (pathtracer.glsl:224-226).
+__global__ __launch_bounds__(256) void k_resolve(FrameArgs f, SceneArgs sc, PixelArgs px)
+{
+	const int L = blockIdx.x * blockDim.x + threadIdx.x;
+	int x, y;
+	if(L >= f.n_local_px || !local_pixel_xy(f, sc.local_blocks, L, &x, &y)) return;
+	float4 acc = px.accum[L];
+	for(int k = 0; k < f.n_frames; ++k)
+	{
+		const float4 r = f.done[(size_t)k * f.n_local_px + L];
+		const float fs = (float)(f.spp + k), fs1 = (float)(f.spp + k + 1);
+		acc = make_float4(fmaf(acc.x, fs, r.x) / fs1, fmaf(acc.y, fs, r.y) / fs1, fmaf(acc.z, fs, r.z) / fs1, 1.0f);
+	}
+	px.accum[L] = acc;
 }
 
 __device__ __forceinline__ int pos_mod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
@@ -258,9 +290,10 @@ __device__ inline F3 align_direction(F3 dir, F3 target)
 }
 
 // main() accumulate of pathtracer.glsl:224-226, executed once per pixel and frame when its path ends
-__device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs &px, int L, F3 ret)
+__device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs &px, int pi, int L, F3 ret)
 {
 	const F3 r = f3(gl_min(ret.x, f.clamp), gl_min(ret.y, f.clamp), gl_min(ret.z, f.clamp));
+	if(f.n_frames > 1) { f.done[pi] = make_float4(r.x, r.y, r.z, 1.0f); return; } // applied in frame order by k_resolve
 	const float4 old = px.accum[L];
 	const float fs = (float)f.spp, fs1 = (float)(f.spp + 1);
 	px.accum[L] = make_float4(fmaf(old.x, fs, r.x) / fs1, fmaf(old.y, fs, r.y) / fs1, fmaf(old.z, fs, r.z) / fs1, 1.0f);
@@ -277,13 +310,21 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 	const uint32_t slot_in = seg * q.seg_cap + local;
 	bool alive = local < n_in;
 	F3 origin = f3(0, 0, 0), dir = f3(0, 0, 1), color = f3(0, 0, 0), ret = f3(0, 0, 0);
-	int L = 0;
+	int L = 0, pi = 0;
+	const float *sobol = f.sobol;
 	bool shaded = false, bad_mat = false;
 	if(alive)
 	{
 		const float4 rd = q.ray_d[slot_in], h = q.hit[slot_in], c4 = q.col[slot_in], r4 = q.rad[slot_in];
 		dir = f3(rd.x, rd.y, rd.z);
-		L = __float_as_int(rd.w);
+		pi = __float_as_int(rd.w);
+		L = pi;
+		if(f.n_frames > 1)
+		{
+			const int frame = (int)((uint32_t)pi / (uint32_t)f.n_local_px);
+			L = pi - frame * f.n_local_px;
+			sobol += frame * 64;
+		}
 		color = f3(c4.x, c4.y, c4.z);
 		ret = f3(r4.x, r4.y, r4.z);
 		const int tri_idx = __float_as_int(h.x);
@@ -319,7 +360,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 				if(illum0 < 6 && dot3(dir, normal) > 0) normal = -normal;
 
 				const uint8_t *sh = px.shift + (size_t)L * 2;
-				const Rng rng{(float)sh[0] / 255.0f, (float)sh[1] / 255.0f, f.sobol};
+				const Rng rng{(float)sh[0] / 255.0f, (float)sh[1] / 255.0f, sobol};
 				int illum = illum0;
 				bool done = false;
 				if(illum == 2)
@@ -382,7 +423,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 				if(b + 1 >= f.max_bounce) alive = false; // last loop iteration
 			}
 		}
-		if(!alive) finish_path(f, px, L, ret);
+		if(!alive) finish_path(f, px, pi, L, ret);
 	}
 	// statistics.  The FetchInfo count is only collected in instrumented runs: even one atomic per wave on a single
 	// word (23 k per launch) costs ~0.27 ms on this chip (~88 same-address atomics/us) — it was 75 % of this kernel.
@@ -399,7 +440,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 	if(alive)
 	{
 		q.out_o[slot] = make_float4(origin.x, origin.y, origin.z, f.tmin);
-		q.out_d[slot] = make_float4(dir.x, dir.y, dir.z, __int_as_float(L));
+		q.out_d[slot] = make_float4(dir.x, dir.y, dir.z, __int_as_float(pi));
 		q.out_col[slot] = make_float4(color.x, color.y, color.z, 0.0f);
 		q.out_rad[slot] = make_float4(ret.x, ret.y, ret.z, 0.0f);
 	}

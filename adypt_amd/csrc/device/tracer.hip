@@ -21,6 +21,7 @@ using namespace adypt;
 namespace {
 
 constexpr int kMaxBounce = 32;
+constexpr int kMaxFramesInFlight = 16;
 
 struct FrameCounters {                 // one memset per frame; every counter on its own 128-byte line
 	uint32_t count[kMaxBounce + 1][kNumSegments * kCursorStride];   // live rays per queue segment after bounce b
@@ -56,6 +57,9 @@ struct adypt_ctx {
 	uint32_t seg_cap = 0;      // slots per XCD-affine segment (multiple of kShadeThreads)
 	float4 *q_o[2] = {nullptr, nullptr}, *q_d[2] = {nullptr, nullptr}, *q_col[2] = {nullptr, nullptr}, *q_rad[2] = {nullptr, nullptr};
 	float4 *d_hit = nullptr;
+	float4 *d_done = nullptr;  // [frames_in_flight][local pixels] finished samples of a multi-frame batch
+	float *d_sobol = nullptr;  // [kMaxFramesInFlight][64] Sobol points of the frames of the current batch
+	int frames_in_flight = 1;
 	RayStats *d_ray_stats = nullptr;
 	FrameCounters *d_counters = nullptr;
 	DeviceStats *d_stats = nullptr;
@@ -241,6 +245,7 @@ void fill_frame(const adypt_ctx *c, FrameArgs *f)
 	f->clamp = c->params.clamp;
 	f->width = c->width; f->height = c->height;
 	f->spp = c->spp; f->subpixel = c->params.subpixel; f->tmp_life = c->params.tmp_lifetime; f->max_bounce = c->params.max_bounce;
+	f->sobol = c->d_sobol; f->done = c->d_done; f->n_frames = 1;
 	f->n_local_px = c->n_local_px; f->blocks_x = c->blocks_x; f->rank = c->rank; f->nranks = c->nranks;
 	f->n_tris = (int32_t)c->n_tris; f->n_mats = (int32_t)c->n_mats; f->n_tex = c->n_tex;
 }
@@ -293,6 +298,33 @@ int load_shift(adypt_ctx *c)
 	}
 	HIP_TRY(c, hipMemcpy(c->d_shift, local.data(), local.size(), hipMemcpyHostToDevice));
 	c->shift_loaded = true; c->shift_seed_loaded = c->params.shift_seed;
+	return ADYPT_OK;
+}
+
+// (re)allocate the wavefront queues for `fif` frames in flight: capacity = fif x local pixels, cut into 8 segments
+int alloc_queues(adypt_ctx *c, int fif)
+{
+	void *old[] = {c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->q_rad[0], c->q_rad[1], c->d_hit, c->d_done, c->d_ray_stats};
+	for(void *b : old) if(b) (void)hipFree(b);
+	c->q_o[0] = c->q_o[1] = c->q_d[0] = c->q_d[1] = c->q_col[0] = c->q_col[1] = c->q_rad[0] = c->q_rad[1] = c->d_hit = c->d_done = nullptr;
+	c->d_ray_stats = nullptr;
+	const size_t npx = (size_t)std::max(c->n_local_px, 64);
+	const size_t paths = npx * (size_t)fif;
+	if(paths >= ((size_t)1 << 31)) return fail(c, ADYPT_E_INVALID, "frames in flight x pixels exceeds 2^31 paths");
+	const size_t chunks = (paths + kShadeThreads - 1) / kShadeThreads;
+	c->seg_cap = (uint32_t)(((chunks + kNumSegments - 1) / kNumSegments) * kShadeThreads);
+	c->capacity = (int64_t)c->seg_cap * kNumSegments;
+	c->frames_in_flight = fif;
+	const size_t nq = (size_t)c->capacity;
+	for(int i = 0; i < 2; ++i)
+	{
+		HIP_TRY(c, hipMalloc((void **)&c->q_o[i], nq * sizeof(float4)));
+		HIP_TRY(c, hipMalloc((void **)&c->q_d[i], nq * sizeof(float4)));
+		HIP_TRY(c, hipMalloc((void **)&c->q_col[i], nq * sizeof(float4)));
+		HIP_TRY(c, hipMalloc((void **)&c->q_rad[i], nq * sizeof(float4)));
+	}
+	HIP_TRY(c, hipMalloc((void **)&c->d_hit, nq * sizeof(float4)));
+	if(fif > 1) HIP_TRY(c, hipMalloc((void **)&c->d_done, paths * sizeof(float4)));
 	return ADYPT_OK;
 }
 
@@ -431,19 +463,13 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	HIP_CREATE(hipMemset(c->d_cache, 0xff, npx * sizeof(float4)));
 	HIP_CREATE(hipMemset(c->d_shift, 0, npx * 2));
 	{
-		const size_t chunks = (npx + kShadeThreads - 1) / kShadeThreads;
-		c->seg_cap = (uint32_t)(((chunks + kNumSegments - 1) / kNumSegments) * kShadeThreads);
-		c->capacity = (int64_t)c->seg_cap * kNumSegments;
+		// frames in flight: enough consecutive frames per wavefront pass to keep ~4 M paths in flight (a tile shard of
+		// an 8-GPU run has only 260 k pixels), at most 8; ADYPT_FRAMES_IN_FLIGHT overrides
+		int fif = (int)std::min<size_t>(8, std::max<size_t>(1, ((size_t)4 << 20) / npx));
+		if(const char *ov = getenv("ADYPT_FRAMES_IN_FLIGHT")) fif = std::max(1, std::min(kMaxFramesInFlight, atoi(ov)));
+		TRY_CREATE(alloc_queues(c, fif));
 	}
-	const size_t nq = (size_t)c->capacity;
-	for(int i = 0; i < 2; ++i)
-	{
-		HIP_CREATE(hipMalloc((void **)&c->q_o[i], nq * sizeof(float4)));
-		HIP_CREATE(hipMalloc((void **)&c->q_d[i], nq * sizeof(float4)));
-		HIP_CREATE(hipMalloc((void **)&c->q_col[i], nq * sizeof(float4)));
-		HIP_CREATE(hipMalloc((void **)&c->q_rad[i], nq * sizeof(float4)));
-	}
-	HIP_CREATE(hipMalloc((void **)&c->d_hit, nq * sizeof(float4)));
+	HIP_CREATE(hipMalloc((void **)&c->d_sobol, (size_t)kMaxFramesInFlight * 64 * sizeof(float)));
 	HIP_CREATE(hipMalloc((void **)&c->d_counters, sizeof(FrameCounters)));
 	HIP_CREATE(hipMalloc((void **)&c->d_stats, sizeof(DeviceStats)));
 	HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(FrameCounters)));
@@ -471,7 +497,7 @@ void adypt_destroy(adypt_ctx *c)
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	void *bufs[] = {c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
 					c->d_accum, c->d_cache, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->q_rad[0], c->q_rad[1],
-					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill};
+					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol};
 	for(void *b : bufs) if(b) (void)hipFree(b);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -517,6 +543,17 @@ int adypt_set_instrumentation(adypt_ctx *c, int flags)
 	return ADYPT_OK;
 }
 
+int adypt_set_frames_in_flight(adypt_ctx *c, int n)
+{
+	if(!c || n < 1 || n > kMaxFramesInFlight) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if(n == c->frames_in_flight) return ADYPT_OK;
+	return alloc_queues(c, n);
+}
+
+int adypt_get_frames_in_flight(const adypt_ctx *c) { return c ? c->frames_in_flight : ADYPT_E_INVALID; }
+
 int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 {
 	if(!c) return ADYPT_E_INVALID;
@@ -559,7 +596,7 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 	fill_scene(c, &sc); fill_pixels(c, &px);
 	const int grid_c = (int)(c->capacity / kShadeThreads); // kNumSegments x chunks per segment
 	const bool stats = (c->instrumentation & 2) != 0;
-	for(int s = 0; s < n_spp; ++s)
+	for(int remaining = n_spp; remaining > 0;)
 	{
 		if(!c->pt_started)
 		{
@@ -570,18 +607,43 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 			c->spp = 0;
 			c->pt_started = true;
 		}
-		const int max_bounce = c->params.max_bounce;
+		const int max_bounce = c->params.max_bounce, life = c->params.tmp_lifetime;
+		// Batch = up to frames_in_flight consecutive frames traced as ONE wavefront (frames are independent samples; the
+		// running mean is applied afterwards in frame order, so the result is bit-identical to frame-by-frame).  A frame
+		// that re-traces its primary rays (spp % tmpLifetime == 0) may only be the first frame of a batch.
+		int m = std::min(remaining, c->frames_in_flight);
+		m = std::min(m, life - c->spp % life);
+		const bool retrace = (c->spp % life) == 0;
 		FrameArgs f;
 		fill_frame(c, &f);
 		{
-			// Sobol::Next (src/Util/Sobol.cpp:16-21): gray-code update with the lowest zero bit of the frame index
-			float pt[64];
-			int r = adypt_sobol_points(2 * max_bounce, c->spp, 1, pt);
+			// Sobol::Next (src/Util/Sobol.cpp:16-21) for the m frames of the batch
+			std::vector<float> pts((size_t)m * 2 * max_bounce), padded((size_t)m * 64, 0.0f);
+			int r = adypt_sobol_points(2 * max_bounce, c->spp, m, pts.data());
 			if(r != ADYPT_OK) return fail(c, r, adypt_host_last_error());
-			memcpy(f.sobol, pt, sizeof(float) * 2 * (size_t)max_bounce);
+			for(int k = 0; k < m; ++k) memcpy(&padded[(size_t)k * 64], &pts[(size_t)k * 2 * max_bounce], sizeof(float) * 2 * (size_t)max_bounce);
+			HIP_TRY(c, hipMemcpyAsync(c->d_sobol, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
 		}
-		const int use_cache = (c->spp % c->params.tmp_lifetime) != 0;
 		HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
+		int use_cache = retrace ? 0 : 1;
+		if(m > 1 && retrace)
+		{
+			// primary-only pass of the re-tracing frame: camera rays -> traversal -> cache image
+			f.n_frames = 1;
+			QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0]);
+			hipEvent_t *stop = begin_timing(c, 1);
+			hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 1);
+			end_timing(c, stop);
+			int r = launch_trace(c, 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, stats, nullptr);
+			if(r != ADYPT_OK) return r;
+			QueueArgs q2 = queue_args(c, 0, c->d_counters->count[0], c->d_counters->count[1]);
+			stop = begin_timing(c, 1);
+			hipLaunchKernelGGL(k_store_cache, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, q2, px);
+			end_timing(c, stop);
+			HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
+			use_cache = 1;
+		}
+		f.n_frames = m;
 		{
 			QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0]); // out = queue 0
 			hipEvent_t *stop = begin_timing(c, 1);
@@ -601,8 +663,15 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 			hipLaunchKernelGGL(k_shade, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
 			end_timing(c, stop);
 		}
+		if(m > 1)
+		{
+			hipEvent_t *stop = begin_timing(c, 1);
+			hipLaunchKernelGGL(k_resolve, dim3((c->n_local_px + 255) / 256), dim3(256), 0, c->stream, f, sc, px);
+			end_timing(c, stop);
+		}
 		HIP_TRY(c, hipGetLastError());
-		++c->spp;
+		c->spp += m;
+		remaining -= m;
 	}
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	harvest_events(c);

@@ -119,6 +119,12 @@ int adypt_trace_primary(adypt_ctx *ctx, int viewer_type);
 int adypt_trace_spp(adypt_ctx *ctx, int n_spp);
 int adypt_reset(adypt_ctx *ctx);
 int adypt_get_spp(const adypt_ctx *ctx); /* OglPathTracer::GetSPP */
+/* How many consecutive frames adypt_trace_spp traces as one wavefront pass (1..16).  Frames are independent
+ * samples and the running mean is applied afterwards in frame order, so results are bit-identical for every value;
+ * more frames in flight keep small images / tile shards saturated.  Default: chosen from the local pixel count
+ * (about 4 M paths per pass, at most 8).  Reallocates the ray queues. */
+int adypt_set_frames_in_flight(adypt_ctx *ctx, int n_frames);
+int adypt_get_frames_in_flight(const adypt_ctx *ctx);
 
 /* glGetTextureImage(m_result_tex, GL_RGB, GL_FLOAT) of OglPathTracer::SaveResult (OglPathTracer.cpp:203-205):
  * W*H*3 floats, row 0 = top of the image.  Pixels of blocks this context does not own are left untouched. */
