@@ -465,7 +465,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	{
 		// frames in flight: enough consecutive frames per wavefront pass to keep ~4 M paths in flight (a tile shard of
 		// an 8-GPU run has only 260 k pixels), at most 8; ADYPT_FRAMES_IN_FLIGHT overrides
-		int fif = (int)std::min<size_t>(8, std::max<size_t>(1, ((size_t)4 << 20) / npx));
+		int fif = (int)std::min<size_t>(kMaxFramesInFlight, std::max<size_t>(1, ((size_t)8 << 20) / npx));
 		if(const char *ov = getenv("ADYPT_FRAMES_IN_FLIGHT")) fif = std::max(1, std::min(kMaxFramesInFlight, atoi(ov)));
 		TRY_CREATE(alloc_queues(c, fif));
 	}

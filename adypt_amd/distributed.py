@@ -72,6 +72,8 @@ def gather_radiance(local, width: int, height: int, rank: int, world: int, group
     if world == 1:
         parts = [local]
     else:
+        if local.is_cuda and dist.get_backend(group) != "nccl":
+            local = local.cpu()  # gloo rehearsal of the N>1 flow: gloo gathers host tensors
         parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
         dist.gather(local, gather_list=parts, dst=0, group=group)  # the single collective of the data path
     if rank != 0:

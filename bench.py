@@ -52,10 +52,15 @@ def main() -> None:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % max(1, torch.cuda.device_count())  # == local_rank on a real multi-GPU node
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("ADYPT_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse the N>1 flow on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from adypt_amd import api, distributed as D, scenes
 
@@ -70,12 +75,12 @@ def main() -> None:
     inst = api.Instance()
     if rank == 0:
         spec = scenes.make_scene(args.scene, args.cache, width=args.width, height=args.height, pt=pt_cfg)
-        ok = inst.InitializeFromFile(spec.config_path, shift_seed=12345, device=local_rank, tile_rank=rank, tile_nranks=world)
+        ok = inst.InitializeFromFile(spec.config_path, shift_seed=12345, device=dev, tile_rank=rank, tile_nranks=world)
         assert ok, api.InstanceConfig.last_error()
     barrier()
     if rank != 0:
         spec = scenes.make_scene(args.scene, args.cache, width=args.width, height=args.height, pt=pt_cfg)
-        ok = inst.InitializeFromFile(spec.config_path, shift_seed=12345, device=local_rank, tile_rank=rank, tile_nranks=world)
+        ok = inst.InitializeFromFile(spec.config_path, shift_seed=12345, device=dev, tile_rank=rank, tile_nranks=world)
         assert ok, api.InstanceConfig.last_error()
     pt = inst.m_path_tracer
     c = inst.m_config.c
@@ -100,8 +105,9 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     st = pt.GetStats()
-    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([int(st["rays"])], dtype=torch.int64, device="cuda")
+    red_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    rays = torch.tensor([int(st["rays"])], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -162,7 +168,7 @@ def main() -> None:
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s-like procedural stand-in (%s), %d triangles, %dx%d, full wavefront path trace, maxBounce %d, tmpLifetime %d, 1 spp per step; one radiance gather per run"
                                       % (args.scene, spec.label, inst.scene.n_tris, c.width, c.height, c.max_bounce, c.tmp_lifetime),
-                          "rays_per_step": round(total_rays / max(1, args.steps)), "tile_shard": "32x32 blocks, owner (bx+by) mod N", "setup_s": round(t_setup, 2)},
+                          "rays_per_step": round(total_rays / max(1, args.steps)), "tile_shard": "32x32 blocks, owner (bx+by) mod N", "frames_in_flight": pt.GetFramesInFlight(), "setup_s": round(t_setup, 2)},
                "roofline": roofline, "cpu_baseline": cpu,
                "shade_kernels_ms": round(shade_ms, 2), "trace_kernels_ms": round(trace_ms, 2),
                "image_mean": float(image.mean()) if image is not None else None}
