@@ -91,6 +91,7 @@ _SIGS = {
     "adypt_read_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adypt_read_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "adypt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    "adypt_trace_rays_any": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "adypt_set_instrumentation": (C.c_int, [C.c_void_p, C.c_int]),
     "adypt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "adypt_reset_stats": (C.c_int, [C.c_void_p]),

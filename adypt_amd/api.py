@@ -349,10 +349,12 @@ class HipPathTracer:
     def SaveResult(self, filename: str, save_as_fp16: bool) -> None:
         save_exr(filename, self.ReadResult(), save_as_fp16)
 
-    def TraceRays(self, rays: np.ndarray, with_stats: bool = True) -> np.ndarray:
+    def TraceRays(self, rays: np.ndarray, with_stats: bool = True, any_hit: bool = False) -> np.ndarray:
+        """closest-hit batch (traversal.glsl:14-255) or, with any_hit, the occlusion overload (traversal.glsl:257-494)."""
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
         hits = np.zeros(len(rays), dtype=HIT_DT)
-        N.check(N.lib.adypt_trace_rays(self._ctx, rays.ctypes.data, len(rays), hits.ctypes.data, 1 if with_stats else 0), self._ctx)
+        fn = N.lib.adypt_trace_rays_any if any_hit else N.lib.adypt_trace_rays
+        N.check(fn(self._ctx, rays.ctypes.data, len(rays), hits.ctypes.data, 1 if with_stats else 0), self._ctx)
         return hits
 
     def SetInstrumentation(self, timing: bool = False, counters: bool = False) -> None:

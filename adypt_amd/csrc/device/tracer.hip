@@ -213,7 +213,7 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	return ensure_spill(c, stack_size);
 }
 
-int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *cursor, int stack_size, bool stats, RayStats *ray_stats)
+int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *cursor, int stack_size, bool stats, RayStats *ray_stats, bool any_hit = false)
 {
 	TraceArgs a;
 	a.nodes = (const uint4 *)c->d_nodes;
@@ -230,7 +230,12 @@ int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *curs
 	a.stack_size = stack_size; a.lds_depth = c->lds_depth;
 	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	hipEvent_t *stop = begin_timing(c, 0);
-	if(c->use_vote)
+	if(any_hit)
+	{
+		if(stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
+		else hipLaunchKernelGGL((k_trace<false, true>), dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
+	}
+	else if(c->use_vote)
 	{
 		if(stats) hipLaunchKernelGGL(k_trace_vote<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
 		else hipLaunchKernelGGL(k_trace_vote<false>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
@@ -715,7 +720,7 @@ int adypt_read_hits(adypt_ctx *c, int32_t *tri, float *uv)
 	return ADYPT_OK;
 }
 
-int adypt_trace_rays(adypt_ctx *c, const float *rays, int64_t n, adypt_hit *hits, int with_stats)
+static int trace_rays_impl(adypt_ctx *c, const float *rays, int64_t n, adypt_hit *hits, int with_stats, bool any_hit)
 {
 	if(!c || n < 0 || (n > 0 && (!rays || !hits))) return ADYPT_E_INVALID;
 	HIP_TRY(c, hipSetDevice(c->device));
@@ -748,7 +753,7 @@ int adypt_trace_rays(adypt_ctx *c, const float *rays, int64_t n, adypt_hit *hits
 			HIP_TRY(c, hipMemcpyAsync(c->q_d[0] + off, d.data() + b0, (size_t)n_s * sizeof(float4), hipMemcpyHostToDevice, c->stream));
 		}
 		HIP_TRY(c, hipMemcpyAsync(c->d_counters->count[0], counts, sizeof(counts), hipMemcpyHostToDevice, c->stream));
-		int r = launch_trace(c, 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, with_stats != 0, with_stats ? c->d_ray_stats : nullptr);
+		int r = launch_trace(c, 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, with_stats != 0, with_stats ? c->d_ray_stats : nullptr, any_hit);
 		if(r != ADYPT_OK) return r;
 		for(int s = 0; s < kNumSegments; ++s)
 		{
@@ -775,6 +780,16 @@ int adypt_trace_rays(adypt_ctx *c, const float *rays, int64_t n, adypt_hit *hits
 	}
 	harvest_events(c);
 	return ADYPT_OK; // stack overflows of arbitrary batches are reported per ray (max_depth = 0xffffffff) and in the stats
+}
+
+int adypt_trace_rays(adypt_ctx *c, const float *rays, int64_t n, adypt_hit *hits, int with_stats)
+{
+	return trace_rays_impl(c, rays, n, hits, with_stats, false);
+}
+
+int adypt_trace_rays_any(adypt_ctx *c, const float *rays, int64_t n, adypt_hit *hits, int with_stats)
+{
+	return trace_rays_impl(c, rays, n, hits, with_stats, true);
 }
 
 int adypt_get_stats(adypt_ctx *c, adypt_stats *out)

@@ -44,7 +44,9 @@ __device__ __forceinline__ uint32_t fetch_rays(const uint32_t *count, uint32_t *
 	return 0;
 }
 
-template <bool STATS>
+// ANY = the any-hit overload of the reference (traversal.glsl:257-494, never called by its shaders — SURVEY.md §8 f1):
+// identical traversal, the ray ends at the FIRST accepted triangle in traversal order.
+template <bool STATS, bool ANY = false>
 __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 {
 	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64]
@@ -180,7 +182,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 			TriPair tp;
 			tp.p0 = tp.p1 = tp.p2 = tp.q0 = tp.q1 = tp.q2 = make_float4(0, 0, 0, 0); tp.tri0 = tp.tri1 = 0; tp.two = false;
 			if(has_tri) load_pair(tp);
-			uint32_t node = 0;
+			uint32_t node = 0, depth_after_push = 0; // push bookkeeping is committed when the node is actually visited (D):
+			bool push_overflow = false;              // an any-hit ray may end before the visit the push belongs to
 			uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0, n4 = n0;
 			if(have_node)
 			{
@@ -194,9 +197,9 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 						if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);
 						else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);
 						++sp;
-						if(STATS) max_depth = max(max_depth, (uint32_t)sp);
+						if(STATS) depth_after_push = (uint32_t)sp;
 					}
-					else overflow = true;
+					else push_overflow = true;
 				}
 				const uint32_t slot = (bit - 24u) ^ octinv;
 				node = ng_x + (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
@@ -211,8 +214,16 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 				for(;;)
 				{
 					test_tri(tp.p0, tp.p1, tp.p2, tp.tri0);
+					if(ANY && hit_idx != -1)
+					{
+						// first accepted triangle ends the ray: nothing after it is tested or visited (traversal.glsl:477-483)
+						if(STATS) n_tris += 1u;
+						have_node = false;
+						break;
+					}
 					if(tp.two) test_tri(tp.q0, tp.q1, tp.q2, tp.tri1);
 					if(STATS) n_tris += tp.two ? 2u : 1u;
+					if(ANY && hit_idx != -1) { have_node = false; break; }
 					if(tg_y == 0) break;
 					load_pair(tp);
 				}
@@ -221,7 +232,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 			if(have_node)
 			{
 				// ---------------- D. slab tests of the fetched node (traversal.glsl:69-205) ----------------
-				if(STATS) { ++n_nodes; hash = (hash * 0x01000193u) ^ node; }
+				overflow |= push_overflow;
+				if(STATS) { ++n_nodes; hash = (hash * 0x01000193u) ^ node; max_depth = max(max_depth, depth_after_push); }
 				const uint32_t octinv4 = octinv * 0x01010101u;
 				const uint32_t head_w = n0.w;
 				const float aix = __uint_as_float((head_w & 0xffu) << 23) * idir.x;

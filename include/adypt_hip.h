@@ -135,6 +135,10 @@ int adypt_read_hits(adypt_ctx *ctx, int32_t *tri, float *uv);
 /* Trace an arbitrary batch of rays through the same traversal kernel: rays = n x 8 floats
  * (ox, oy, oz, tmin, dx, dy, dz, unused).  with_stats selects the instrumented kernel variant. */
 int adypt_trace_rays(adypt_ctx *ctx, const float *rays, int64_t n, adypt_hit *hits, int with_stats);
+/* The any-hit overload `bool BVHIntersection(origin_tmin, dir)` (traversal.glsl:257-494; present in the reference but
+ * never called by its shaders): same traversal, every ray stops at the FIRST accepted triangle in traversal order.
+ * hits[i].tri_id != -1  <=>  the GLSL function returns true; u, v, t describe that first accepted triangle. */
+int adypt_trace_rays_any(adypt_ctx *ctx, const float *rays, int64_t n, adypt_hit *hits, int with_stats);
 
 /* instrumentation: bit 0 = per-launch HIP-event timing, bit 1 = instrumented traversal (node/triangle counts) */
 int adypt_set_instrumentation(adypt_ctx *ctx, int flags);

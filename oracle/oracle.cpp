@@ -228,7 +228,8 @@ static inline int find_lsb(uint32_t x) { return __builtin_ctz(x); }
 
 static const int kMaxStack = 64;
 
-static void bvh_intersect(const OrcScene &sc, int stack_size, const float o4[4], V3 dir, OrcHit *out)
+// any_hit = the second overload, shaders/traversal.glsl:257-494: identical, returns at the first accepted triangle
+static void bvh_intersect(const OrcScene &sc, int stack_size, const float o4[4], V3 dir, OrcHit *out, bool any_hit = false)
 {
 	const Node *nodes = (const Node *)sc.nodes;
 	const Woop *woop = (const Woop *)sc.woop;
@@ -343,6 +344,7 @@ static void bvh_intersect(const OrcScene &sc, int stack_size, const float o4[4],
 					if(tv >= 0.0f && tu + tv <= 1.0f)
 					{
 						hit_t = tt; hit_u = tu; hit_v = tv; hit_idx = (int32_t)tridx;
+						if(any_hit) goto done; // traversal.glsl:477-483 `return true`
 					}
 		}
 
@@ -353,6 +355,7 @@ static void bvh_intersect(const OrcScene &sc, int stack_size, const float o4[4],
 			ng_x = stack[stack_ptr][0]; ng_y = stack[stack_ptr][1];
 		}
 	}
+done:
 	out->ref_idx = hit_idx;
 	out->tri_id = hit_idx != -1 ? sc.tri_indices[hit_idx] : -1; // :253-254
 	out->u = hit_u; out->v = hit_v; out->t = hit_t;
@@ -735,15 +738,24 @@ ORC_API void orc_sincos(const float *x, int n, float *s, float *c) { for(int i =
 ORC_API void orc_pow(const float *x, const float *y, int n, float *out) { for(int i = 0; i < n; ++i) out[i] = canon_pow(x[i], y[i]); }
 
 // rays: n * 8 floats (ox, oy, oz, tmin, dx, dy, dz, unused)
-ORC_API void orc_trace(const OrcScene *sc, int stack_size, const float *rays, int64_t n, OrcHit *hits, int n_threads)
+static void trace_batch(const OrcScene *sc, int stack_size, const float *rays, int64_t n, OrcHit *hits, int n_threads, bool any_hit)
 {
 	const int64_t chunk = 4096;
 	int n_chunks = (int)((n + chunk - 1) / chunk);
 	parallel_rows(n_chunks, n_threads, [&](int ci, int) {
 		int64_t b = (int64_t)ci * chunk, e = b + chunk < n ? b + chunk : n;
 		for(int64_t i = b; i < e; ++i)
-			bvh_intersect(*sc, stack_size, rays + i * 8, v3(rays[i * 8 + 4], rays[i * 8 + 5], rays[i * 8 + 6]), hits + i);
+			bvh_intersect(*sc, stack_size, rays + i * 8, v3(rays[i * 8 + 4], rays[i * 8 + 5], rays[i * 8 + 6]), hits + i, any_hit);
 	});
+}
+ORC_API void orc_trace(const OrcScene *sc, int stack_size, const float *rays, int64_t n, OrcHit *hits, int n_threads)
+{
+	trace_batch(sc, stack_size, rays, n, hits, n_threads, false);
+}
+// any-hit overload (traversal.glsl:257-494): hits[i].tri_id != -1  <=>  the GLSL function returns true
+ORC_API void orc_trace_any(const OrcScene *sc, int stack_size, const float *rays, int64_t n, OrcHit *hits, int n_threads)
+{
+	trace_batch(sc, stack_size, rays, n, hits, n_threads, true);
 }
 
 // primaryray.glsl main (:46-94).  rgba: W*H*4.  hits (optional): W*H OrcHit records.

@@ -187,12 +187,12 @@ def pow_(x: np.ndarray, y: np.ndarray) -> np.ndarray:
     return out
 
 
-def trace(scene: Scene, rays: np.ndarray, stack_size: int = 24, n_threads: Optional[int] = None) -> np.ndarray:
-    """rays: (n, 8) float32 = ox oy oz tmin dx dy dz pad.  Returns HIT_DT[n]."""
+def trace(scene: Scene, rays: np.ndarray, stack_size: int = 24, n_threads: Optional[int] = None, any_hit: bool = False) -> np.ndarray:
+    """rays: (n, 8) float32 = ox oy oz tmin dx dy dz pad.  Returns HIT_DT[n].  any_hit: traversal.glsl:257-494."""
     rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
     hits = np.empty(len(rays), dtype=HIT_DT)
-    lib().orc_trace(C.byref(scene._c), C.c_int(stack_size), _p(rays), C.c_int64(len(rays)), _p(hits),
-                    C.c_int(n_threads or default_threads()))
+    fn = lib().orc_trace_any if any_hit else lib().orc_trace
+    fn(C.byref(scene._c), C.c_int(stack_size), _p(rays), C.c_int64(len(rays)), _p(hits), C.c_int(n_threads or default_threads()))
     return hits
 
 
