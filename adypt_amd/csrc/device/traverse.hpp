@@ -47,7 +47,7 @@ __device__ __forceinline__ uint32_t fetch_rays(const uint32_t *count, uint32_t *
 // ANY = the any-hit overload of the reference (traversal.glsl:257-494, never called by its shaders — SURVEY.md §8 f1):
 // identical traversal, the ray ends at the FIRST accepted triangle in traversal order.
 template <bool STATS, bool ANY = false>
-__global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
+__global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_trace(TraceArgs a) // hot variant: <= 96 VGPRs
 {
 	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64]
 	const int lane = threadIdx.x & 63;
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 						++sp;
 						if(STATS) depth_after_push = (uint32_t)sp;
 					}
-					else push_overflow = true;
+					else if(ANY) push_overflow = true;
+					else overflow = true; // closest hit: the visit always follows, commit right away (one register less)
 				}
 				const uint32_t slot = (bit - 24u) ^ octinv;
 				node = ng_x + (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
@@ -232,9 +233,10 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 			if(have_node)
 			{
 				// ---------------- D. slab tests of the fetched node (traversal.glsl:69-205) ----------------
-				overflow |= push_overflow;
+				if(ANY) overflow |= push_overflow;
 				if(STATS) { ++n_nodes; hash = (hash * 0x01000193u) ^ node; max_depth = max(max_depth, depth_after_push); }
-				const uint32_t octinv4 = octinv * 0x01010101u;
+				// octinv replicated into the 4 bytes: v_perm_b32 with selector 0 instead of a quarter-rate v_mul_lo_u32
+				const uint32_t octinv4 = __builtin_amdgcn_perm(0u, octinv, 0u);
 				const uint32_t head_w = n0.w;
 				const float aix = __uint_as_float((head_w & 0xffu) << 23) * idir.x;
 				const float aiy = __uint_as_float(((head_w >> 8) & 0xffu) << 23) * idir.y;
@@ -250,7 +252,9 @@ __global__ __launch_bounds__(kTraceThreads) void k_trace(TraceArgs a)
 				{
 					const uint32_t meta4 = g ? n1.w : n1.z;
 					const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-					const uint32_t bit_index4 = (meta4 ^ (octinv4 & ((is_inner4 >> 4) * 0xffu))) & 0x1f1f1f1fu;
+					// per-byte select mask for octinv (<= 7): (b << 3) - b = 7 for inner bytes, no multiply, no cross-byte borrow
+					const uint32_t inner1 = is_inner4 >> 4;
+					const uint32_t bit_index4 = (meta4 ^ (octinv4 & ((inner1 << 3) - inner1))) & 0x1f1f1f1fu;
 					const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
 					const uint32_t qlox = g ? n2.y : n2.x, qloy = g ? n2.w : n2.z, qloz = g ? n3.y : n3.x;
 					const uint32_t qhix = g ? n3.w : n3.z, qhiy = g ? n4.y : n4.x, qhiz = g ? n4.w : n4.z;
