@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadypt_hip.so")
+LIB_PATH = os.environ.get("ADYPT_LIB", os.path.join(_HERE, "libadypt_hip.so"))  # ADYPT_LIB: measurement-only variant builds
 
 ADYPT_OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_OOM, E_STACK_OVERFLOW, E_BAD_MATERIAL, E_IO, E_PARSE, E_STATE = range(-1, -10, -1)

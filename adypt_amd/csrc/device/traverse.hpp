@@ -164,8 +164,8 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				t.tri0 = tg_x + b0; t.tri1 = tg_x + b1;
 				const float4 *w0 = a.woop + (size_t)t.tri0 * 3, *w1 = a.woop + (size_t)t.tri1 * 3;
 				t.p0 = w0[0]; t.p1 = w0[1]; t.p2 = w0[2];
-				t.q0 = w1[0]; t.q1 = w1[1]; t.q2 = w1[2];
-			};
+				t.q0 = w1[0]; t.q1 = w1[1]; t.q2 = w1[2]; // unconditional (tri1 == tri0 for a single triangle): a predicated
+			};                                            // second fetch measured 3 % slower (extra branch, split load batch)
 			// Woop test of one triangle (traversal.glsl:219-242)
 			auto test_tri = [&](const float4 &m0, const float4 &m1, const float4 &m2, uint32_t tri) {
 				const float toz = m0.w - dot3(origin, f3(m0.x, m0.y, m0.z));
@@ -206,6 +206,14 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				node = ng_x + (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
 				const uint4 *np = a.nodes + (size_t)node * 5;
 				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
+#ifdef ADYPT_ABLATE_EXTRA_LOADS
+				{	// measurement-only build: issue the same 5 loads a second time (L1 hits) to price the vector-memory issue path
+					const uint4 *np2 = np;
+					asm volatile("" : "+v"(np2)); // launder the pointer so the duplicate loads are not CSE'd
+					const uint4 e0 = np2[0], e1 = np2[1], e2 = np2[2], e3 = np2[3], e4 = np2[4];
+					asm volatile("" :: "v"(e0.x), "v"(e0.w), "v"(e1.x), "v"(e1.w), "v"(e2.x), "v"(e2.w), "v"(e3.x), "v"(e3.w), "v"(e4.x), "v"(e4.w));
+				}
+#endif
 			}
 			__builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting arithmetic between the load issues
 
