@@ -562,6 +562,10 @@ _SCENE_TABLE = {
     # name: (builder, seed, default detail, camera, W, H)
     "sponza": ("atrium", 2, 1.0, {"fov": 45.0, "yaw": 270.0, "pitch": 0.0, "position": [-13.0, 2.2, 0.3]}),
     "sibenik": ("cathedral", 1, 1.0, {"fov": 50.0, "yaw": 270.0, "pitch": 5.0, "position": [-18.0, 3.0, 0.0]}),
+    # "salle-de-bain-like" (~1.2 M triangles) and "san-miguel-like" (~10 M): the same atrium generator at higher
+    # tessellation (triangle count grows with detail^2); stand-ins for BASELINE.json configs 5 and 4
+    "salle": ("atrium", 4, 2.2, {"fov": 50.0, "yaw": 250.0, "pitch": -8.0, "position": [-11.0, 3.5, 2.5]}),
+    "sanmiguel": ("atrium", 3, 6.35, {"fov": 55.0, "yaw": 285.0, "pitch": 4.0, "position": [-12.5, 7.5, -1.0]}),
     "tiny0": ("tiny0", 10, 1.0, {"fov": 45.0, "yaw": 0.0, "pitch": -10.0, "position": [0.0, 2.0, 6.5]}),
     "tiny1": ("tiny1", 11, 1.0, {"fov": 60.0, "yaw": 200.0, "pitch": -25.0, "position": [1.5, 4.0, -6.0]}),
     "tiny2": ("tiny2", 12, 1.0, {"fov": 60.0, "yaw": 180.0, "pitch": 0.0, "position": [6.0, 0.5, -10.0]}),

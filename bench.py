@@ -128,7 +128,7 @@ def main() -> None:
     # per ray 80 B x nodes visited + 48 B x triangles tested + 4 B x hit remap + 32 B ray read + 16 B hit write
     alg_bytes = 80 * cs["nodes_visited"] + 48 * cs["tris_tested"] + 4 * cs["hits"] + 48 * cs["rays"]
     achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_trace<false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_trace<false, false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "launches": int(trace_launches), "avg_launch_ms": round(trace_ms / max(1, trace_launches), 4),
                 "alg_bytes_per_launch": round(alg_bytes / max(1, trace_launches)), "alg_bytes_per_ray": round(alg_bytes / max(1, cs["rays"]), 1),
@@ -136,6 +136,17 @@ def main() -> None:
                 "trace_kernel_Mrays_s": round(st["rays"] / (trace_ms * 1e3), 1) if trace_ms > 0 else None,
                 "note": "algorithmic bytes / HIP-event time of the traversal launches of rank 0; the BVH (nodes+Woop %.0f MB) is Infinity-Cache resident, so real HBM traffic is lower" %
                         ((len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 48) / 1e6)}
+
+    # `traffic`: HBM/fabric bytes per launch of the same kernel from the PMC counters (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024,
+    # gfx950 corrections of MI355X_MICROARCH.md).  Counters cannot be read from inside this process; the value comes
+    # from the committed rocprofv3 --pmc passes over this very command (tools/collect_profiles.sh -> profiles/r1_pmc_traffic.json).
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        if world == 1 and (args.scene, args.width, args.height) == ("sponza", 1920, 1080):
+            roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
+            roofline["traffic_source"] = "profiles/r1_pmc_traffic.json (separate rocprofv3 --pmc passes of bench.py --steps 16 --warmup 4); L2 hit rate %.2f" % pmc["TCC_hit_rate"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     # ---- CPU baseline: the oracle's scalar traversal + shading of the same workload, bounded sample ---------------------
     cpu = None
