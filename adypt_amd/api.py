@@ -365,6 +365,12 @@ class HipPathTracer:
         N.check(N.lib.adypt_get_stats(self._ctx, C.byref(st)), self._ctx)
         return st.as_dict()
 
+    def GetWaveProfile(self) -> dict:
+        out = (C.c_uint64 * 8)()
+        N.check(N.lib.adypt_get_wave_profile(self._ctx, out), self._ctx)
+        keys = ("trips", "trip_lanes", "tri_iters", "tri_lanes", "node_phases", "node_lanes", "refills", "empty_trips")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def ResetStats(self) -> None:
         N.check(N.lib.adypt_reset_stats(self._ctx), self._ctx)
 

@@ -38,6 +38,7 @@ constexpr int kTriFloat4 = 7;                  // device triangle record: 7 x fl
 struct DeviceStats {                           // accumulated until adypt_reset_stats
 	unsigned long long rays, nodes, tris, hits, shaded, overflows, bad_materials;
 	uint32_t max_stack, pad;
+	unsigned long long wave_profile[8];          // adypt_get_wave_profile (instrumented traversal only)
 };
 
 struct RayStats { int32_t ref_idx; uint32_t nodes, tris, hash, max_depth, pad0, pad1, pad2; }; // 32 B, STATS variant

@@ -559,7 +559,8 @@ int adypt_set_instrumentation(adypt_ctx *c, int flags)
 
 int adypt_set_frames_in_flight(adypt_ctx *c, int n)
 {
-	if(!c || n < 1 || n > kMaxFramesInFlight) return ADYPT_E_INVALID;
+	if(!c) return ADYPT_E_INVALID;
+	if(n < 1 || n > kMaxFramesInFlight) return fail(c, ADYPT_E_INVALID, "adypt_set_frames_in_flight: n_frames must be in [1, " + std::to_string(kMaxFramesInFlight) + "]");
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	if(n == c->frames_in_flight) return ADYPT_OK;
@@ -803,6 +804,17 @@ int adypt_get_stats(adypt_ctx *c, adypt_stats *out)
 	out->rays = st.rays; out->nodes_visited = st.nodes; out->tris_tested = st.tris; out->hits = st.hits; out->shaded = st.shaded;
 	out->stack_overflows = st.overflows; out->bad_materials = st.bad_materials; out->max_stack = st.max_stack;
 	out->trace_launches = c->trace_launches; out->trace_ms = c->trace_ms; out->shade_ms = c->shade_ms;
+	return ADYPT_OK;
+}
+
+int adypt_get_wave_profile(adypt_ctx *c, uint64_t out[8])
+{
+	if(!c || !out) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	DeviceStats st;
+	HIP_TRY(c, hipMemcpy(&st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+	for(int i = 0; i < 8; ++i) out[i] = st.wave_profile[i];
 	return ADYPT_OK;
 }
 

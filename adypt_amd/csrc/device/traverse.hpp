@@ -76,11 +76,20 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 	uint32_t ng_x = 0, ng_y = 0, tg_x = 0, tg_y = 0;
 	uint32_t n_nodes = 0, n_tris = 0, hash = 0, max_depth = 0;
 	bool overflow = false;
+	bool pending = false;                        // a next node is chosen (and pushed for) but not yet slab-tested
+	uint32_t node = 0, depth_after_push = 0;     // push bookkeeping is committed when the node is actually visited (D)
+	bool push_overflow = false;
 
 	unsigned long long st_nodes = 0, st_tris = 0, st_hits = 0;
 	uint32_t st_maxdepth = 0;
 	bool any_overflow = false, exhausted = false;
 	uint32_t loc_next = 0, loc_end = 0; // wave-uniform: reserved but not yet started rays
+	unsigned long long wp[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // STATS: wave-occupancy profile (adypt_get_wave_profile)
+	// one count per wave-level event, taken by the first lane that executes it, plus the number of lanes executing it
+	auto wave_event = [&](int slot) {
+		const unsigned long long m = __ballot(true);
+		if(lane == (int)__builtin_ctzll(m)) { wp[slot] += 1; wp[slot + 1] += (unsigned long long)__popcll(m); }
+	};
 
 	for(;;)
 	{
@@ -101,6 +110,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			const uint32_t begin = loc_next;
 			const uint32_t got = min(n_idle, loc_end - loc_next);
 			loc_next += got;
+			if(STATS && lane == 0) wp[6] += 1;
 			const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
 			if(!active && my_rank < got)
 			{
@@ -126,84 +136,88 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				sp = 0;
 				ng_x = 0; ng_y = 0x80000000u; tg_x = 0; tg_y = 0;
 				if(STATS) { n_nodes = 0; n_tris = 0; hash = 0x811c9dc5u; max_depth = 0; }
-				overflow = false;
+				overflow = false; pending = false; push_overflow = false; depth_after_push = 0;
 				active = true;
 			}
 		}
-		if(__ballot(active) == 0ull)
+		const unsigned long long live = __ballot(active);
+		if(STATS && lane == 0) { wp[0] += 1; wp[1] += (unsigned long long)__popcll(live); }
+		if(live == 0ull)
 		{
+			if(STATS && lane == 0) wp[7] += 1;
 			if(exhausted && loc_next == loc_end) break;
 			continue;
 		}
 
 		if(active)
 		{
-			// ---------------- A. choose the next node (traversal.glsl:47-66 / 245-250) ----------------
-			bool have_node = true;
-			if(ng_y <= 0x00ffffffu)
+			// One trip = at most one triangle PAIR and at most one slab test per lane.  A lane whose node produced more
+			// than two triangles keeps its already chosen next node pending and simply fetches it again on the following
+			// trip (an L1/L2 hit): measured with adypt_get_wave_profile, an inner loop over all pairs ran 2.4 iterations per
+			// trip with 6 of 64 lanes live — 40 % of the kernel's VALU slots at 9 % utilisation.
+			// ---------------- A. choose the next node (traversal.glsl:47-66 / 245-250) unless one is pending ----------------
+			if(!pending)
 			{
-				if(sp == 0) have_node = false;
-				else
+				pending = true;
+				if(ng_y <= 0x00ffffffu)
 				{
-					--sp;
-					const uint2 g = sp < a.lds_depth ? my_stack[sp * 64] : my_spill[(size_t)(sp - a.lds_depth) * total_lanes];
-					ng_x = g.x; ng_y = g.y;
-					// complete the pop here (LDS read, or the rare spill read from global memory) so that no older
-					// memory operation is pending when the triangle / node loads below are issued
-					asm volatile("" : "+v"(ng_x), "+v"(ng_y));
+					if(sp == 0) pending = false;
+					else
+					{
+						--sp;
+						const uint2 g = sp < a.lds_depth ? my_stack[sp * 64] : my_spill[(size_t)(sp - a.lds_depth) * total_lanes];
+						ng_x = g.x; ng_y = g.y;
+						// complete the pop here (LDS read, or the rare spill read from global memory) so that no older
+						// memory operation is pending when the triangle / node loads below are issued
+						asm volatile("" : "+v"(ng_x), "+v"(ng_y));
+					}
+				}
+				if(pending)
+				{
+					const uint32_t imask = ng_y;
+					const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng_y);
+					ng_y &= ~(1u << bit);
+					if(ng_y > 0x00ffffffu)
+					{
+						if(sp < a.stack_size)
+						{
+							if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);
+							else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);
+							++sp;
+							if(STATS) depth_after_push = (uint32_t)sp;
+						}
+						else if(ANY) push_overflow = true; // an any-hit ray may end before the visit the push belongs to
+						else overflow = true;              // closest hit: the visit always follows, commit right away
+					}
+					const uint32_t slot = (bit - 24u) ^ octinv;
+					node = ng_x + (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
 				}
 			}
-			// ---------------- B. issue every load of this trip back to back: first triangle pair, then the next node ------
+			// ---------------- B. issue every load of this trip back to back: one triangle pair, then the pending node ------
 			struct TriPair { float4 p0, p1, p2, q0, q1, q2; uint32_t tri0, tri1; bool two; };
-			auto load_pair = [&](TriPair &t) {
-				const uint32_t b0 = (uint32_t)__builtin_ctz(tg_y);
-				tg_y &= tg_y - 1u;
-				t.two = tg_y != 0;
-				const uint32_t b1 = t.two ? (uint32_t)__builtin_ctz(tg_y) : b0;
-				tg_y &= tg_y - 1u; // no-op when tg_y is already 0
-				t.tri0 = tg_x + b0; t.tri1 = tg_x + b1;
-				const float4 *w0 = a.woop + (size_t)t.tri0 * 3, *w1 = a.woop + (size_t)t.tri1 * 3;
-				t.p0 = w0[0]; t.p1 = w0[1]; t.p2 = w0[2];
-				t.q0 = w1[0]; t.q1 = w1[1]; t.q2 = w1[2]; // unconditional (tri1 == tri0 for a single triangle): a predicated
-			};                                            // second fetch measured 3 % slower (extra branch, split load batch)
-			// Woop test of one triangle (traversal.glsl:219-242)
-			auto test_tri = [&](const float4 &m0, const float4 &m1, const float4 &m2, uint32_t tri) {
-				const float toz = m0.w - dot3(origin, f3(m0.x, m0.y, m0.z));
-				const float tidz = 1.0f / dot3(dir, f3(m0.x, m0.y, m0.z));
-				const float tt = toz * tidz;
-				const float tu = fmaf(tt, dot3(dir, f3(m1.x, m1.y, m1.z)), m1.w + dot3(origin, f3(m1.x, m1.y, m1.z)));
-				const float tv = fmaf(tt, dot3(dir, f3(m2.x, m2.y, m2.z)), m2.w + dot3(origin, f3(m2.x, m2.y, m2.z)));
-				if(tt > tmin && tt < hit_t && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f)
-				{
-					hit_t = tt; hit_u = tu; hit_v = tv; hit_idx = (int32_t)tri;
-				}
-			};
 			const bool has_tri = tg_y != 0;
 			TriPair tp;
-			tp.p0 = tp.p1 = tp.p2 = tp.q0 = tp.q1 = tp.q2 = make_float4(0, 0, 0, 0); tp.tri0 = tp.tri1 = 0; tp.two = false;
-			if(has_tri) load_pair(tp);
-			uint32_t node = 0, depth_after_push = 0; // push bookkeeping is committed when the node is actually visited (D):
-			bool push_overflow = false;              // an any-hit ray may end before the visit the push belongs to
-			uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0, n3 = n0, n4 = n0;
-			if(have_node)
+			// registers only read under has_tri / pending: "defined" by an empty asm (no instruction) instead of zero-filled —
+			// leaving them uninitialised makes the register allocator spill, zero-filling costs 45 VALU slots per trip
+#define ADYPT_DEF4(v) asm volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))
+			ADYPT_DEF4(tp.p0); ADYPT_DEF4(tp.p1); ADYPT_DEF4(tp.p2); ADYPT_DEF4(tp.q0); ADYPT_DEF4(tp.q1); ADYPT_DEF4(tp.q2);
+			asm volatile("" : "=v"(tp.tri0), "=v"(tp.tri1)); tp.two = false;
+			if(has_tri)
 			{
-				const uint32_t imask = ng_y;
-				const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng_y);
-				ng_y &= ~(1u << bit);
-				if(ng_y > 0x00ffffffu)
-				{
-					if(sp < a.stack_size)
-					{
-						if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);
-						else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);
-						++sp;
-						if(STATS) depth_after_push = (uint32_t)sp;
-					}
-					else if(ANY) push_overflow = true;
-					else overflow = true; // closest hit: the visit always follows, commit right away (one register less)
-				}
-				const uint32_t slot = (bit - 24u) ^ octinv;
-				node = ng_x + (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
+				const uint32_t b0 = (uint32_t)__builtin_ctz(tg_y);
+				tg_y &= tg_y - 1u;
+				tp.two = tg_y != 0;
+				const uint32_t b1 = tp.two ? (uint32_t)__builtin_ctz(tg_y) : b0;
+				tg_y &= tg_y - 1u; // no-op when tg_y is already 0
+				tp.tri0 = tg_x + b0; tp.tri1 = tg_x + b1;
+				const float4 *w0 = a.woop + (size_t)tp.tri0 * 3, *w1 = a.woop + (size_t)tp.tri1 * 3;
+				tp.p0 = w0[0]; tp.p1 = w0[1]; tp.p2 = w0[2];
+				tp.q0 = w1[0]; tp.q1 = w1[1]; tp.q2 = w1[2]; // unconditional (tri1 == tri0 for a single triangle): a predicated
+			}                                                // second fetch measured 3 % slower (extra branch, split load batch)
+			uint4 n0, n1, n2, n3, n4;
+			ADYPT_DEF4(n0); ADYPT_DEF4(n1); ADYPT_DEF4(n2); ADYPT_DEF4(n3); ADYPT_DEF4(n4);
+			if(pending)
+			{
 				const uint4 *np = a.nodes + (size_t)node * 5;
 				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
 #ifdef ADYPT_ABLATE_EXTRA_LOADS
@@ -217,31 +231,46 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			}
 			__builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting arithmetic between the load issues
 
-			// ---------------- C. triangles of the node visited last (traversal.glsl:213-243), two per trip ----------------
+			// ---------------- C. one pair of the triangles of the node visited last (traversal.glsl:213-243) ----------------
+			// Woop test of one triangle (traversal.glsl:219-242)
+			auto test_tri = [&](const float4 &m0, const float4 &m1, const float4 &m2, uint32_t tri) {
+				const float toz = m0.w - dot3(origin, f3(m0.x, m0.y, m0.z));
+				const float tidz = 1.0f / dot3(dir, f3(m0.x, m0.y, m0.z));
+				const float tt = toz * tidz;
+				const float tu = fmaf(tt, dot3(dir, f3(m1.x, m1.y, m1.z)), m1.w + dot3(origin, f3(m1.x, m1.y, m1.z)));
+				const float tv = fmaf(tt, dot3(dir, f3(m2.x, m2.y, m2.z)), m2.w + dot3(origin, f3(m2.x, m2.y, m2.z)));
+				if(tt > tmin && tt < hit_t && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f)
+				{
+					hit_t = tt; hit_u = tu; hit_v = tv; hit_idx = (int32_t)tri;
+				}
+			};
 			if(has_tri)
 			{
-				for(;;)
+				if(STATS) wave_event(2);
+				test_tri(tp.p0, tp.p1, tp.p2, tp.tri0);
+				if(ANY && hit_idx != -1)
 				{
-					test_tri(tp.p0, tp.p1, tp.p2, tp.tri0);
-					if(ANY && hit_idx != -1)
-					{
-						// first accepted triangle ends the ray: nothing after it is tested or visited (traversal.glsl:477-483)
-						if(STATS) n_tris += 1u;
-						have_node = false;
-						break;
-					}
+					// first accepted triangle ends the ray: nothing after it is tested or visited (traversal.glsl:477-483)
+					if(STATS) n_tris += 1u;
+				}
+				else
+				{
 					if(tp.two) test_tri(tp.q0, tp.q1, tp.q2, tp.tri1);
 					if(STATS) n_tris += tp.two ? 2u : 1u;
-					if(ANY && hit_idx != -1) { have_node = false; break; }
-					if(tg_y == 0) break;
-					load_pair(tp);
 				}
+				if(ANY && hit_idx != -1) { tg_y = 0; pending = false; }
 			}
 
-			if(have_node)
+			if(tg_y != 0)
+			{
+				// more triangles of this node: next trip (the pending node is fetched again then)
+			}
+			else if(pending)
 			{
 				// ---------------- D. slab tests of the fetched node (traversal.glsl:69-205) ----------------
+				pending = false;
 				if(ANY) overflow |= push_overflow;
+				if(STATS) wave_event(4);
 				if(STATS) { ++n_nodes; hash = (hash * 0x01000193u) ^ node; max_depth = max(max_depth, depth_after_push); }
 				// octinv replicated into the 4 bytes: v_perm_b32 with selector 0 instead of a quarter-rate v_mul_lo_u32
 				const uint32_t octinv4 = __builtin_amdgcn_perm(0u, octinv, 0u);
@@ -319,9 +348,11 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			st_tris += __shfl_down(st_tris, off);
 			st_hits += __shfl_down(st_hits, off);
 			st_maxdepth = max(st_maxdepth, (uint32_t)__shfl_down((int)st_maxdepth, off));
+			for(int i = 0; i < 8; ++i) wp[i] += __shfl_down(wp[i], off);
 		}
 		if(lane == 0)
 		{
+			for(int i = 0; i < 8; ++i) atomicAdd(&a.stats->wave_profile[i], wp[i]);
 			atomicAdd(&a.stats->nodes, st_nodes);
 			atomicAdd(&a.stats->tris, st_tris);
 			atomicAdd(&a.stats->hits, st_hits);

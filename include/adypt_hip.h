@@ -144,6 +144,11 @@ int adypt_trace_rays_any(adypt_ctx *ctx, const float *rays, int64_t n, adypt_hit
 int adypt_set_instrumentation(adypt_ctx *ctx, int flags);
 int adypt_get_stats(adypt_ctx *ctx, adypt_stats *out);
 int adypt_reset_stats(adypt_ctx *ctx);
+/* SIMD-occupancy profile of the instrumented traversal launches since the last reset (measurement only; wave-level
+ * sums): out[0] loop trips, [1] lanes holding a ray summed over trips, [2] triangle-pair iterations, [3] lanes active
+ * summed over those, [4] slab-test phases executed, [5] lanes active summed over those, [6] refill events,
+ * [7] trips with no lane holding a ray. */
+int adypt_get_wave_profile(adypt_ctx *ctx, uint64_t out[8]);
 
 /* ---- pixel-tile sharding plumbing (multi-GPU: one context per GPU/process, one gather per output frame) ---- */
 /* number of RGBA float4 elements in the compact local radiance buffer (owned blocks x 1024 pixels) */
