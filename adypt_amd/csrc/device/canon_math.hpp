@@ -23,6 +23,12 @@ __device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y 
 __device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ F3 fma3(F3 a, float s, F3 c) { return f3(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z)); }
 __device__ __forceinline__ F3 fma3(F3 a, F3 b, F3 c) { return f3(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z)); }
+// two binary32 values in adjacent registers: +, * and pk_fma map to v_pk_add/mul/fma_f32 — each half is the same IEEE
+// operation as the scalar instruction, so packing never changes a result
+typedef float V2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ V2 v2s(float s) { V2 r; r.x = s; r.y = s; return r; }
+__device__ __forceinline__ V2 pk_fma(V2 a, V2 b, V2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 __device__ __forceinline__ F3 cross3(F3 a, F3 b)
 {

@@ -67,7 +67,10 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 	// per-lane ray state
 	bool active = false;
 	uint32_t ray = 0;
-	F3 origin = f3(0, 0, 0), dir = f3(0, 0, 1), idir = f3(0, 0, 1);
+	// origin and direction are kept interleaved per axis — (o.x,d.x), (o.y,d.y), (o.z,d.z) in adjacent registers — so one
+	// v_pk_fma_f32 advances o·m and d·m of a Woop row together (same products, same fma order as dot3: bit-identical)
+	V2 od_x = v2(0, 0), od_y = v2(0, 0), od_z = v2(0, 1);
+	F3 idir = f3(0, 0, 1);
 	bool nx = false, ny = false, nz = false;
 	uint32_t octinv = 7u;
 	float tmin = 0.0f, hit_t = 1e9f, hit_u = 0.0f, hit_v = 0.0f;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				const float4 ro = a.ray_o[ray];
 				const float4 rd = a.ray_d[ray];
 				const float ooeps = __uint_as_float((127u - 64u) << 23);
-				dir = f3(rd.x, rd.y, rd.z);
+				F3 dir = f3(rd.x, rd.y, rd.z);
 				dir.x = fabsf(dir.x) > ooeps ? dir.x : (dir.x >= 0 ? ooeps : -ooeps);
 				dir.y = fabsf(dir.y) > ooeps ? dir.y : (dir.y >= 0 ? ooeps : -ooeps);
 				dir.z = fabsf(dir.z) > ooeps ? dir.z : (dir.z >= 0 ? ooeps : -ooeps);
@@ -127,11 +130,12 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				idir = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 				nx = dir.x < 0; ny = dir.y < 0; nz = dir.z < 0;
 				octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
-				origin = f3(ro.x, ro.y, ro.z);
+				F3 origin = f3(ro.x, ro.y, ro.z);
 				tmin = ro.w;
 				// make the ray loads complete inside this (rare) refill block: otherwise the compiler's s_waitcnt
 				// bookkeeping carries them into the traversal loop and drains the software-pipelined node fetch
 				asm volatile("" : "+v"(origin.x), "+v"(origin.y), "+v"(origin.z), "+v"(tmin));
+				od_x = v2(origin.x, dir.x); od_y = v2(origin.y, dir.y); od_z = v2(origin.z, dir.z);
 				hit_t = 1e9f; hit_u = 0.0f; hit_v = 0.0f; hit_idx = -1;
 				sp = 0;
 				ng_x = 0; ng_y = 0x80000000u; tg_x = 0; tg_y = 0;
@@ -234,11 +238,15 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			// ---------------- C. one pair of the triangles of the node visited last (traversal.glsl:213-243) ----------------
 			// Woop test of one triangle (traversal.glsl:219-242)
 			auto test_tri = [&](const float4 &m0, const float4 &m1, const float4 &m2, uint32_t tri) {
-				const float toz = m0.w - dot3(origin, f3(m0.x, m0.y, m0.z));
-				const float tidz = 1.0f / dot3(dir, f3(m0.x, m0.y, m0.z));
+				// (o·m, d·m) per row: x = dot3(origin, m.xyz), y = dot3(dir, m.xyz)
+				const V2 r0 = pk_fma(od_z, v2s(m0.z), pk_fma(od_y, v2s(m0.y), od_x * v2s(m0.x)));
+				const V2 r1 = pk_fma(od_z, v2s(m1.z), pk_fma(od_y, v2s(m1.y), od_x * v2s(m1.x)));
+				const V2 r2 = pk_fma(od_z, v2s(m2.z), pk_fma(od_y, v2s(m2.y), od_x * v2s(m2.x)));
+				const float toz = m0.w - r0.x;
+				const float tidz = 1.0f / r0.y;
 				const float tt = toz * tidz;
-				const float tu = fmaf(tt, dot3(dir, f3(m1.x, m1.y, m1.z)), m1.w + dot3(origin, f3(m1.x, m1.y, m1.z)));
-				const float tv = fmaf(tt, dot3(dir, f3(m2.x, m2.y, m2.z)), m2.w + dot3(origin, f3(m2.x, m2.y, m2.z)));
+				const float tu = fmaf(tt, r1.y, m1.w + r1.x);
+				const float tv = fmaf(tt, r2.y, m2.w + r2.x);
 				if(tt > tmin && tt < hit_t && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f)
 				{
 					hit_t = tt; hit_u = tu; hit_v = tv; hit_idx = (int32_t)tri;
@@ -278,9 +286,9 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				const float aix = __uint_as_float((head_w & 0xffu) << 23) * idir.x;
 				const float aiy = __uint_as_float(((head_w >> 8) & 0xffu) << 23) * idir.y;
 				const float aiz = __uint_as_float(((head_w >> 16) & 0xffu) << 23) * idir.z;
-				const float aox = (__uint_as_float(n0.x) - origin.x) * idir.x;
-				const float aoy = (__uint_as_float(n0.y) - origin.y) * idir.y;
-				const float aoz = (__uint_as_float(n0.z) - origin.z) * idir.z;
+				const float aox = (__uint_as_float(n0.x) - od_x.x) * idir.x;
+				const float aoy = (__uint_as_float(n0.y) - od_y.x) * idir.y;
+				const float aoz = (__uint_as_float(n0.z) - od_z.x) * idir.z;
 				ng_x = n1.x;
 				tg_x = n1.y;
 				uint32_t hitmask = 0;
@@ -302,14 +310,12 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 					for(int j = 0; j < 4; ++j)
 					{
 						const int sh = 8 * j;
-						const float txmin = fmaf((float)((slox >> sh) & 0xffu), aix, aox);
-						const float tymin = fmaf((float)((sloy >> sh) & 0xffu), aiy, aoy);
-						const float tzmin = fmaf((float)((sloz >> sh) & 0xffu), aiz, aoz);
-						const float txmax = fmaf((float)((shix >> sh) & 0xffu), aix, aox);
-						const float tymax = fmaf((float)((shiy >> sh) & 0xffu), aiy, aoy);
-						const float tzmax = fmaf((float)((shiz >> sh) & 0xffu), aiz, aoz);
-						const float cmin = fmaxf(fmaxf(txmin, tymin), fmaxf(tzmin, tmin));   // IEEE maxNum / minNum
-						const float cmax = fminf(fminf(txmax, tymax), fminf(tzmax, hit_t));
+						// (entry, exit) distance of one axis in one v_pk_fma_f32: t = fma(float(q), adj_idir, adj_org)
+						const V2 tx = pk_fma(v2((float)((slox >> sh) & 0xffu), (float)((shix >> sh) & 0xffu)), v2s(aix), v2s(aox));
+						const V2 ty = pk_fma(v2((float)((sloy >> sh) & 0xffu), (float)((shiy >> sh) & 0xffu)), v2s(aiy), v2s(aoy));
+						const V2 tz = pk_fma(v2((float)((sloz >> sh) & 0xffu), (float)((shiz >> sh) & 0xffu)), v2s(aiz), v2s(aoz));
+						const float cmin = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));   // IEEE maxNum / minNum
+						const float cmax = fminf(fminf(tx.y, ty.y), fminf(tz.y, hit_t));
 						if(cmin <= cmax) hitmask |= ((child_bits4 >> sh) & 0xffu) << ((bit_index4 >> sh) & 0xffu);
 					}
 				}
