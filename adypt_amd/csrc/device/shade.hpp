@@ -57,7 +57,6 @@ struct TraceArgs {
 	uint32_t seg_cap;              // slots per segment
 	int32_t stack_size, lds_depth;
 	uint32_t refill_min, chunk;    // tunables of the persistent fetch (traverse.hpp)
-	uint32_t tri_min;              // k_trace_vote: run the triangle phase when at least this many lanes wait for it
 };
 
 // ---------------------------------------------------------------------------------------------------------------

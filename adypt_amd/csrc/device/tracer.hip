@@ -5,7 +5,7 @@
 //     memset counters -> k_gen_primary -> [ k_trace -> k_shade ] x maxBounce      (all on ctx->stream, no host sync;
 //     queue sizes live in device memory, the traversal kernel is persistent, the shade grid covers the worst case)
 // There is no CPU fallback anywhere in this file: without a HIP device adypt_create fails with ADYPT_E_NO_DEVICE.
-#include "traverse_vote.hpp"
+#include "traverse.hpp"
 #include "../../../include/adypt_hip.h"
 #include "../../../include/adypt_host.h"
 
@@ -68,8 +68,7 @@ struct adypt_ctx {
 
 	// launch geometry of the persistent traversal kernel
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0, occupancy_api = 0;
-	uint32_t refill_min = kRefillMin, chunk = kChunk, tri_min = 16;
-	bool use_vote = false;
+	uint32_t refill_min = kRefillMin, chunk = kChunk;
 
 	// state
 	adypt_pt_params params{}, pending{};
@@ -204,8 +203,7 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	c->lds_depth = std::max(1, std::min(stack_size, kLdsStackMax));
 	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	int per_cu = 0;
-	if(c->use_vote) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_vote<false>, kTraceThreads, lds));
-	else HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
+	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
 	c->occupancy_api = per_cu;
 	per_cu = std::max(1, std::min(per_cu, 8));
 	if(const char *ov = getenv("ADYPT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(16, atoi(ov))); // tuning override
@@ -226,7 +224,7 @@ int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *curs
 	a.spill = c->d_spill;
 	a.stats = c->d_stats;
 	a.seg_cap = c->seg_cap;
-	a.refill_min = c->refill_min; a.chunk = c->chunk; a.tri_min = c->tri_min;
+	a.refill_min = c->refill_min; a.chunk = c->chunk;
 	a.stack_size = stack_size; a.lds_depth = c->lds_depth;
 	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	hipEvent_t *stop = begin_timing(c, 0);
@@ -234,11 +232,6 @@ int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *curs
 	{
 		if(stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
 		else hipLaunchKernelGGL((k_trace<false, true>), dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
-	}
-	else if(c->use_vote)
-	{
-		if(stats) hipLaunchKernelGGL(k_trace_vote<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
-		else hipLaunchKernelGGL(k_trace_vote<false>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
 	}
 	else if(stats) hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
 	else hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
@@ -419,8 +412,6 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	c->num_cus = prop.multiProcessorCount;
 	if(const char *ov = getenv("ADYPT_REFILL_MIN")) c->refill_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
-	if(const char *ov = getenv("ADYPT_TRI_MIN")) c->tri_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
-	if(const char *ov = getenv("ADYPT_TRACE_VOTE")) c->use_vote = atoi(ov) != 0;
 
 	c->n_nodes = d->n_nodes; c->n_refs = d->n_refs; c->n_tris = d->n_tris; c->n_mats = d->n_mats; c->n_tex = d->n_textures;
 	c->width = d->width; c->height = d->height; c->rank = d->tile_rank; c->nranks = d->tile_nranks;

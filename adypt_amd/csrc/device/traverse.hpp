@@ -26,20 +26,26 @@ constexpr int kChunk = 128;    // default: rays reserved per queue atomic
 
 // Reserve up to `want` consecutive rays: first from the segment of "our" XCD (blockIdx & 7 groups the workgroups
 // that share an L2 under the observed round-robin dispatch — a speed hint only), then steal from the others.
-__device__ __forceinline__ uint32_t fetch_rays(const uint32_t *count, uint32_t *cursor, uint32_t seg_cap, int home, uint32_t want, uint32_t *begin)
+// One device atomic and nothing else per reservation: the segment lengths are read once per wave (lane s of
+// `seg_len_lanes` holds count[s]) and a segment found exhausted is remembered in `seg_done`, so the three dependent
+// global round trips of the first version (count, cursor pre-check, atomic) shrink to one — measured: reservations
+// were 18 % of the kernel's time at 128 rays per reservation.
+__device__ __forceinline__ uint32_t fetch_rays(uint32_t seg_len_lanes, uint32_t &seg_done, uint32_t *cursor, uint32_t seg_cap, int home, uint32_t want, uint32_t *begin)
 {
 	for(int k = 0; k < kNumSegments; ++k)
 	{
 		const int s = (home + k) & (kNumSegments - 1);
-		const uint32_t seg_len = count[s * kCursorStride];
-		if(seg_len == 0) continue;
-		if(__hip_atomic_load(&cursor[s * kCursorStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seg_len) continue;
-		const uint32_t rel = atomicAdd(&cursor[s * kCursorStride], want);
+		if((seg_done >> s) & 1u) continue;
+		const uint32_t seg_len = (uint32_t)__builtin_amdgcn_readlane((int)seg_len_lanes, s);
+		uint32_t rel = 0;
+		if(threadIdx.x % 64 == 0) rel = atomicAdd(&cursor[s * kCursorStride], want);
+		rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
 		if(rel < seg_len)
 		{
 			*begin = (uint32_t)s * seg_cap + rel;
 			return min(want, seg_len - rel);
 		}
+		seg_done |= 1u << s;
 	}
 	return 0;
 }
@@ -87,6 +93,10 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 	uint32_t st_maxdepth = 0;
 	bool any_overflow = false, exhausted = false;
 	uint32_t loc_next = 0, loc_end = 0; // wave-uniform: reserved but not yet started rays
+	const uint32_t seg_len_lanes = lane < kNumSegments ? a.count[lane * kCursorStride] : 0u;
+	uint32_t seg_done = 0;              // wave-uniform: segments found empty or exhausted
+	for(int sgm = 0; sgm < kNumSegments; ++sgm)
+		if(__builtin_amdgcn_readlane((int)seg_len_lanes, sgm) == 0) seg_done |= 1u << sgm;
 	unsigned long long wp[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // STATS: wave-occupancy profile (adypt_get_wave_profile)
 	// one count per wave-level event, taken by the first lane that executes it, plus the number of lanes executing it
 	auto wave_event = [&](int slot) {
@@ -103,10 +113,8 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 		{
 			if(loc_next == loc_end)
 			{
-				uint32_t cb = 0, cn = 0;
-				if(lane == 0) cn = fetch_rays(a.count, a.cursor, a.seg_cap, home, a.chunk, &cb);
-				cn = __builtin_amdgcn_readfirstlane(cn);
-				cb = __builtin_amdgcn_readfirstlane(cb);
+				uint32_t cb = 0;
+				const uint32_t cn = fetch_rays(seg_len_lanes, seg_done, a.cursor, a.seg_cap, home, a.chunk, &cb);
 				loc_next = cb; loc_end = cb + cn;
 				if(cn == 0) exhausted = true;
 			}
@@ -160,43 +168,39 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			// trip (an L1/L2 hit): measured with adypt_get_wave_profile, an inner loop over all pairs ran 2.4 iterations per
 			// trip with 6 of 64 lanes live — 40 % of the kernel's VALU slots at 9 % utilisation.
 			// ---------------- A. choose the next node (traversal.glsl:47-66 / 245-250) unless one is pending ----------------
-			if(!pending)
+			// (flat sequence of predicated steps rather than nested branches: every nesting level made the compiler copy
+			// the loop-carried ray state)
+			const bool can_pop = !pending && ng_y <= 0x00ffffffu && sp != 0;
+			if(can_pop)
 			{
-				pending = true;
-				if(ng_y <= 0x00ffffffu)
-				{
-					if(sp == 0) pending = false;
-					else
-					{
-						--sp;
-						const uint2 g = sp < a.lds_depth ? my_stack[sp * 64] : my_spill[(size_t)(sp - a.lds_depth) * total_lanes];
-						ng_x = g.x; ng_y = g.y;
-						// complete the pop here (LDS read, or the rare spill read from global memory) so that no older
-						// memory operation is pending when the triangle / node loads below are issued
-						asm volatile("" : "+v"(ng_x), "+v"(ng_y));
-					}
-				}
-				if(pending)
-				{
-					const uint32_t imask = ng_y;
-					const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng_y);
-					ng_y &= ~(1u << bit);
-					if(ng_y > 0x00ffffffu)
-					{
-						if(sp < a.stack_size)
-						{
-							if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);
-							else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);
-							++sp;
-							if(STATS) depth_after_push = (uint32_t)sp;
-						}
-						else if(ANY) push_overflow = true; // an any-hit ray may end before the visit the push belongs to
-						else overflow = true;              // closest hit: the visit always follows, commit right away
-					}
-					const uint32_t slot = (bit - 24u) ^ octinv;
-					node = ng_x + (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
-				}
+				--sp;
+				const uint2 g = sp < a.lds_depth ? my_stack[sp * 64] : my_spill[(size_t)(sp - a.lds_depth) * total_lanes];
+				ng_x = g.x; ng_y = g.y;
+				// complete the pop here (LDS read, or the rare spill read from global memory) so that no older
+				// memory operation is pending when the triangle / node loads below are issued
+				asm volatile("" : "+v"(ng_x), "+v"(ng_y));
 			}
+			const bool choose = !pending && ng_y > 0x00ffffffu;
+			if(choose)
+			{
+				const uint32_t imask = ng_y;
+				const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng_y);
+				ng_y &= ~(1u << bit);
+				const uint32_t slot = (bit - 24u) ^ octinv;
+				node = ng_x + (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
+				pending = true;
+			}
+			const bool push = choose && ng_y > 0x00ffffffu;
+			const bool push_ok = push && sp < a.stack_size;
+			if(push_ok)
+			{
+				if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);
+				else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);
+				++sp;
+				if(STATS) depth_after_push = (uint32_t)sp;
+			}
+			if(ANY) push_overflow |= push && !push_ok; // an any-hit ray may end before the visit the push belongs to
+			else overflow |= push && !push_ok;         // closest hit: the visit always follows, commit right away
 			// ---------------- B. issue every load of this trip back to back: one triangle pair, then the pending node ------
 			struct TriPair { float4 p0, p1, p2, q0, q1, q2; uint32_t tri0, tri1; bool two; };
 			const bool has_tri = tg_y != 0;

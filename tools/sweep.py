@@ -20,6 +20,6 @@ def run(env, frames=12):
     p.destroy()
 run({})
 for r in (4, 8, 12, 24, 32): run({"ADYPT_REFILL_MIN": r})
-for c in (64, 256, 512): run({"ADYPT_CHUNK": c})
+for c in (64, 96, 192, 256, 384, 512): run({"ADYPT_CHUNK": c})
 for b in (3, 4, 5, 6): run({"ADYPT_TRACE_BLOCKS_PER_CU": b})
 run({"ADYPT_REFILL_MIN": 8, "ADYPT_TRACE_BLOCKS_PER_CU": 5})
