@@ -86,9 +86,9 @@ struct SceneArgs {
 };
 
 struct QueueArgs {
-	float4 *ray_o, *ray_d, *col, *rad;   // queue being read (shade) / written (gen)
-	float4 *hit;
-	float4 *out_o, *out_d, *out_col, *out_rad;
+	float4 *ray_o, *ray_d, *col;   // queue being read (shade) / written (gen); col.w != 0 <=> the path has radiance parked
+	float4 *hit;                   //   in FrameArgs::done[path] (emission picked up so far) — it does not travel in the queue
+	float4 *out_o, *out_d, *out_col;
 	const uint32_t *count_in;      // [s * kCursorStride]
 	uint32_t *count_out;           // [s * kCursorStride]
 	uint32_t seg_cap;
@@ -177,7 +177,6 @@ __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, Scen
 	q.out_o[slot] = make_float4(f.origin[0], f.origin[1], f.origin[2], f.tmin);
 	q.out_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float((int)pi));
 	q.out_col[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-	q.out_rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	if(use_cache) q.hit[slot] = px.cache[L];
 }
 
@@ -294,7 +293,8 @@ __device__ inline F3 align_direction(F3 dir, F3 target)
 __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs &px, int pi, int L, F3 ret)
 {
 	const F3 r = f3(gl_min(ret.x, f.clamp), gl_min(ret.y, f.clamp), gl_min(ret.z, f.clamp));
-	if(f.n_frames > 1) { f.done[pi] = make_float4(r.x, r.y, r.z, 1.0f); return; } // applied in frame order by k_resolve
+	if(f.n_frames > 1) { f.done[pi] = make_float4(r.x, r.y, r.z, 1.0f); return; } // applied in frame order by k_resolve (the
+	                                                                               // slot doubles as the parked radiance of a live path)
 	const float4 old = px.accum[L];
 	const float fs = (float)f.spp, fs1 = (float)(f.spp + 1);
 	px.accum[L] = make_float4(fmaf(old.x, fs, r.x) / fs1, fmaf(old.y, fs, r.y) / fs1, fmaf(old.z, fs, r.z) / fs1, 1.0f);
@@ -302,7 +302,7 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 
 // One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for every live path.
 // store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
-__global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int b, int store_cache, int count_stats)
+__global__ __launch_bounds__(kShadeThreads, 6) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int b, int store_cache, int count_stats)
 {
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	const uint32_t n_in = q.count_in[seg * kCursorStride];
@@ -313,10 +313,11 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 	F3 origin = f3(0, 0, 0), dir = f3(0, 0, 1), color = f3(0, 0, 0), ret = f3(0, 0, 0);
 	int L = 0, pi = 0;
 	const float *sobol = f.sobol;
-	bool shaded = false, bad_mat = false;
+	bool shaded = false, bad_mat = false, parked = false;
+	F3 ret_in = f3(0, 0, 0);
 	if(alive)
 	{
-		const float4 rd = q.ray_d[slot_in], h = q.hit[slot_in], c4 = q.col[slot_in], r4 = q.rad[slot_in];
+		const float4 rd = q.ray_d[slot_in], h = q.hit[slot_in], c4 = q.col[slot_in];
 		dir = f3(rd.x, rd.y, rd.z);
 		pi = __float_as_int(rd.w);
 		L = pi;
@@ -327,7 +328,11 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 			sobol += frame * 64;
 		}
 		color = f3(c4.x, c4.y, c4.z);
-		ret = f3(r4.x, r4.y, r4.z);
+		// radiance picked up so far: zero for almost every path, so it is parked per path (FrameArgs::done[pi]) and only
+		// touched when it changes, instead of being read and re-written (32 B) by every bounce of every path
+		parked = c4.w != 0.0f;
+		if(parked) { const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); }
+		ret_in = ret;
 		const int tri_idx = __float_as_int(h.x);
 		const float tu = h.y, tv = h.z;
 		if(store_cache) px.cache[L] = make_float4(h.x, tu, tv, 0.0f);
@@ -442,8 +447,13 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(FrameArgs f, SceneArgs 
 	{
 		q.out_o[slot] = make_float4(origin.x, origin.y, origin.z, f.tmin);
 		q.out_d[slot] = make_float4(dir.x, dir.y, dir.z, __int_as_float(pi));
-		q.out_col[slot] = make_float4(color.x, color.y, color.z, 0.0f);
-		q.out_rad[slot] = make_float4(ret.x, ret.y, ret.z, 0.0f);
+		if(__float_as_uint(ret.x) != __float_as_uint(ret_in.x) || __float_as_uint(ret.y) != __float_as_uint(ret_in.y) ||
+		   __float_as_uint(ret.z) != __float_as_uint(ret_in.z))
+		{
+			f.done[pi] = make_float4(ret.x, ret.y, ret.z, 0.0f);
+			parked = true;
+		}
+		q.out_col[slot] = make_float4(color.x, color.y, color.z, parked ? 1.0f : 0.0f);
 	}
 }
 

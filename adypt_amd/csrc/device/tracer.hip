@@ -55,7 +55,7 @@ struct adypt_ctx {
 	// wavefront queues
 	int64_t capacity = 0;      // queue slots = kNumSegments * seg_cap
 	uint32_t seg_cap = 0;      // slots per XCD-affine segment (multiple of kShadeThreads)
-	float4 *q_o[2] = {nullptr, nullptr}, *q_d[2] = {nullptr, nullptr}, *q_col[2] = {nullptr, nullptr}, *q_rad[2] = {nullptr, nullptr};
+	float4 *q_o[2] = {nullptr, nullptr}, *q_d[2] = {nullptr, nullptr}, *q_col[2] = {nullptr, nullptr};
 	float4 *d_hit = nullptr;
 	float4 *d_done = nullptr;  // [frames_in_flight][local pixels] finished samples of a multi-frame batch
 	float *d_sobol = nullptr;  // [kMaxFramesInFlight][64] Sobol points of the frames of the current batch
@@ -269,9 +269,9 @@ void fill_pixels(const adypt_ctx *c, PixelArgs *p)
 QueueArgs queue_args(adypt_ctx *c, int in, const uint32_t *count_in, uint32_t *count_out)
 {
 	QueueArgs q;
-	q.ray_o = c->q_o[in]; q.ray_d = c->q_d[in]; q.col = c->q_col[in]; q.rad = c->q_rad[in];
+	q.ray_o = c->q_o[in]; q.ray_d = c->q_d[in]; q.col = c->q_col[in];
 	q.hit = c->d_hit;
-	q.out_o = c->q_o[in ^ 1]; q.out_d = c->q_d[in ^ 1]; q.out_col = c->q_col[in ^ 1]; q.out_rad = c->q_rad[in ^ 1];
+	q.out_o = c->q_o[in ^ 1]; q.out_d = c->q_d[in ^ 1]; q.out_col = c->q_col[in ^ 1];
 	q.count_in = count_in; q.count_out = count_out;
 	q.seg_cap = c->seg_cap;
 	return q;
@@ -309,9 +309,9 @@ int load_shift(adypt_ctx *c)
 // (re)allocate the wavefront queues for `fif` frames in flight: capacity = fif x local pixels, cut into 8 segments
 int alloc_queues(adypt_ctx *c, int fif)
 {
-	void *old[] = {c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->q_rad[0], c->q_rad[1], c->d_hit, c->d_done, c->d_ray_stats};
+	void *old[] = {c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->d_hit, c->d_done, c->d_ray_stats};
 	for(void *b : old) if(b) (void)hipFree(b);
-	c->q_o[0] = c->q_o[1] = c->q_d[0] = c->q_d[1] = c->q_col[0] = c->q_col[1] = c->q_rad[0] = c->q_rad[1] = c->d_hit = c->d_done = nullptr;
+	c->q_o[0] = c->q_o[1] = c->q_d[0] = c->q_d[1] = c->q_col[0] = c->q_col[1] = c->d_hit = c->d_done = nullptr;
 	c->d_ray_stats = nullptr;
 	const size_t npx = (size_t)std::max(c->n_local_px, 64);
 	const size_t paths = npx * (size_t)fif;
@@ -326,10 +326,9 @@ int alloc_queues(adypt_ctx *c, int fif)
 		HIP_TRY(c, hipMalloc((void **)&c->q_o[i], nq * sizeof(float4)));
 		HIP_TRY(c, hipMalloc((void **)&c->q_d[i], nq * sizeof(float4)));
 		HIP_TRY(c, hipMalloc((void **)&c->q_col[i], nq * sizeof(float4)));
-		HIP_TRY(c, hipMalloc((void **)&c->q_rad[i], nq * sizeof(float4)));
 	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_hit, nq * sizeof(float4)));
-	if(fif > 1) HIP_TRY(c, hipMalloc((void **)&c->d_done, paths * sizeof(float4)));
+	HIP_TRY(c, hipMalloc((void **)&c->d_done, paths * sizeof(float4))); // finished samples of a batch / parked radiance of live paths
 	return ADYPT_OK;
 }
 
@@ -470,7 +469,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	{
 		// frames in flight: enough consecutive frames per wavefront pass to keep ~4 M paths in flight (a tile shard of
 		// an 8-GPU run has only 260 k pixels), at most 8; ADYPT_FRAMES_IN_FLIGHT overrides
-		int fif = (int)std::min<size_t>(kMaxFramesInFlight, std::max<size_t>(1, ((size_t)8 << 20) / npx));
+		int fif = (int)std::min<size_t>(kMaxFramesInFlight, std::max<size_t>(1, ((size_t)32 << 20) / npx)); // ~32 M paths per wavefront pass: the drain of a launch (its longest rays) is amortised over more work
 		if(const char *ov = getenv("ADYPT_FRAMES_IN_FLIGHT")) fif = std::max(1, std::min(kMaxFramesInFlight, atoi(ov)));
 		TRY_CREATE(alloc_queues(c, fif));
 	}
@@ -501,7 +500,7 @@ void adypt_destroy(adypt_ctx *c)
 	for(EventPair &p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	void *bufs[] = {c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
-					c->d_accum, c->d_cache, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->q_rad[0], c->q_rad[1],
+					c->d_accum, c->d_cache, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
 					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol};
 	for(void *b : bufs) if(b) (void)hipFree(b);
 	if(c->stream) (void)hipStreamDestroy(c->stream);

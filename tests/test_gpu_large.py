@@ -44,7 +44,7 @@ def test_salle_4096_frame_bit_exact(salle, sobol_matrices):
     assert np.isfinite(a).all() and a.max() <= c.clamp
     # determinism and frames-in-flight invariance at this size
     auto = pt.GetFramesInFlight()
-    pt.SetFramesInFlight(2)
+    pt.SetFramesInFlight(1 if auto != 1 else 2)
     pt.Reset()
     pt.Trace(True, 2)
     assert np.array_equal(bits(pt.ReadResult()), bits(a))
