@@ -70,7 +70,9 @@ struct FrameArgs {
 	float4 *done;                  // device: [frame in batch][local pixel] finished sample radiance (batches of > 1 frame only)
 	int32_t width, height;
 	int32_t spp, subpixel, tmp_life, max_bounce; // spp = index of the FIRST frame of the batch
-	int32_t n_frames;              // frames in flight in this pass (path index = frame * n_local_px + local pixel)
+	int32_t n_frames;              // frames in flight in this pass (path index = frame ordinal * n_local_px + local pixel)
+	int32_t frame_first, frame_stride; // batch frame of ordinal r = frame_first + r * frame_stride (main pass: 0, 1; the
+	                               //   primary-only pass runs just the re-tracing frames of the batch: first one, tmp_life)
 	int32_t n_local_px;            // owned blocks * 1024
 	int32_t blocks_x;              // image width in 32-px blocks
 	int32_t rank, nranks;
@@ -97,6 +99,8 @@ struct QueueArgs {
 struct PixelArgs {
 	float4 *accum;                 // running mean RGBA per local pixel   (image 0)
 	float4 *cache;                 // cached primary hit per local pixel  (image 1)
+	float4 *cache_next;            // batches spanning several tmpLifetime groups: primary hits of group 1, 2, ... of the
+	                               //   batch, [group - 1][local pixel]; group 0 (the batch's first frame) lives in `cache`
 	const uint8_t *shift;          // 2 bytes per local pixel             (image 2)
 	DeviceStats *stats;
 };
@@ -109,6 +113,13 @@ __device__ __forceinline__ bool local_pixel_xy(const FrameArgs &f, const int32_t
 	*x = bx * kBlockDim + (wt & 3) * 8 + (ln & 7);
 	*y = by * kBlockDim + (wt >> 2) * 8 + (ln >> 3);
 	return *x < f.width && *y < f.height;
+}
+
+// tmpLifetime group of batch frame `frame`, relative to the group of the batch's first frame (f.spp)
+__device__ __forceinline__ int frame_group(const FrameArgs &f, int frame) { return (f.spp + frame) / f.tmp_life - f.spp / f.tmp_life; }
+__device__ __forceinline__ float4 *cache_of_group(const FrameArgs &f, const PixelArgs &px, int group)
+{
+	return group == 0 ? px.cache : px.cache_next + (size_t)(group - 1) * (size_t)f.n_local_px;
 }
 
 __device__ __forceinline__ F3 camera_dir(const FrameArgs &f, int px, int py, float bx, float by)
@@ -160,9 +171,10 @@ __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, Scen
 	// each segment takes a contiguous run of local pixels (= whole 32x32 blocks of the image): XCD-local coherence
 	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
 	const uint32_t pi = seg * q.seg_cap + local; // path index = frame * n_local_px + local pixel
-	const int frame = (int)(pi / (uint32_t)f.n_local_px), L = (int)(pi % (uint32_t)f.n_local_px);
+	const int ordinal = (int)(pi / (uint32_t)f.n_local_px), L = (int)(pi % (uint32_t)f.n_local_px);
+	const int frame = f.frame_first + ordinal * f.frame_stride;
 	int x = 0, y = 0;
-	const bool alive = local < q.seg_cap && frame < f.n_frames && local_pixel_xy(f, sc.local_blocks, L, &x, &y);
+	const bool alive = local < q.seg_cap && ordinal < f.n_frames && local_pixel_xy(f, sc.local_blocks, L, &x, &y);
 	float bx = 0.0f, by = 0.0f;
 	if(bias_mode)
 	{
@@ -177,20 +189,22 @@ __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, Scen
 	q.out_o[slot] = make_float4(f.origin[0], f.origin[1], f.origin[2], f.tmin);
 	q.out_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float((int)pi));
 	q.out_col[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-	if(use_cache) q.hit[slot] = px.cache[L];
+	if(use_cache) q.hit[slot] = cache_of_group(f, px, frame_group(f, frame))[L];
 }
 
-// Batches of several frames: the frame that re-traces its primary rays (spp % tmpLife == 0) runs a primary-only
-// pass first and parks the hits in the cache image (pathtracer.glsl:121-127); every frame of the batch then starts
-// from the cache.
-__global__ __launch_bounds__(kShadeThreads) void k_store_cache(QueueArgs q, PixelArgs px)
+// Batches of several frames: the frames that re-trace their primary rays (spp % tmpLife == 0) run a primary-only
+// pass first and park the hits in the cache image of their tmpLifetime group (pathtracer.glsl:121-127); every frame
+// of the batch then starts from the cache of its group.
+__global__ __launch_bounds__(kShadeThreads) void k_store_cache(FrameArgs f, QueueArgs q, PixelArgs px)
 {
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
 	if(local >= q.count_in[seg * kCursorStride]) return;
 	const uint32_t slot = seg * q.seg_cap + local;
 	const float4 h = q.hit[slot];
-	px.cache[__float_as_int(q.ray_d[slot].w)] = make_float4(h.x, h.y, h.z, 0.0f); // primary pass: path index == local pixel
+	const uint32_t pi = (uint32_t)__float_as_int(q.ray_d[slot].w); // primary pass: ordinal of the re-tracing frame, local pixel
+	const int ordinal = (int)(pi / (uint32_t)f.n_local_px), L = (int)(pi % (uint32_t)f.n_local_px);
+	cache_of_group(f, px, frame_group(f, f.frame_first + ordinal * f.frame_stride))[L] = make_float4(h.x, h.y, h.z, 0.0f);
 }
 
 // Applies the finished samples of a batch to the running mean in frame order (pathtracer.glsl:224-226).

@@ -21,7 +21,7 @@ using namespace adypt;
 namespace {
 
 constexpr int kMaxBounce = 32;
-constexpr int kMaxFramesInFlight = 16;
+constexpr int kMaxFramesInFlight = 128;
 
 struct FrameCounters {                 // one memset per frame; every counter on its own 128-byte line
 	uint32_t count[kMaxBounce + 1][kNumSegments * kCursorStride];   // live rays per queue segment after bounce b
@@ -50,6 +50,8 @@ struct adypt_ctx {
 
 	// per local pixel
 	float4 *d_accum = nullptr, *d_cache = nullptr;
+	float4 *d_cache_next = nullptr; // primary hits of the 2nd, 3rd, ... tmpLifetime group of a batch (shade.hpp PixelArgs)
+	int cache_next_slices = 0;
 	uint8_t *d_shift = nullptr;
 
 	// wavefront queues
@@ -250,7 +252,7 @@ void fill_frame(const adypt_ctx *c, FrameArgs *f)
 	f->clamp = c->params.clamp;
 	f->width = c->width; f->height = c->height;
 	f->spp = c->spp; f->subpixel = c->params.subpixel; f->tmp_life = c->params.tmp_lifetime; f->max_bounce = c->params.max_bounce;
-	f->sobol = c->d_sobol; f->done = c->d_done; f->n_frames = 1;
+	f->sobol = c->d_sobol; f->done = c->d_done; f->n_frames = 1; f->frame_first = 0; f->frame_stride = 1;
 	f->n_local_px = c->n_local_px; f->blocks_x = c->blocks_x; f->rank = c->rank; f->nranks = c->nranks;
 	f->n_tris = (int32_t)c->n_tris; f->n_mats = (int32_t)c->n_mats; f->n_tex = c->n_tex;
 }
@@ -264,7 +266,7 @@ void fill_scene(const adypt_ctx *c, SceneArgs *s)
 }
 void fill_pixels(const adypt_ctx *c, PixelArgs *p)
 {
-	p->accum = c->d_accum; p->cache = c->d_cache; p->shift = c->d_shift; p->stats = c->d_stats;
+	p->accum = c->d_accum; p->cache = c->d_cache; p->cache_next = c->d_cache_next; p->shift = c->d_shift; p->stats = c->d_stats;
 }
 QueueArgs queue_args(adypt_ctx *c, int in, const uint32_t *count_in, uint32_t *count_out)
 {
@@ -329,6 +331,17 @@ int alloc_queues(adypt_ctx *c, int fif)
 	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_hit, nq * sizeof(float4)));
 	HIP_TRY(c, hipMalloc((void **)&c->d_done, paths * sizeof(float4))); // finished samples of a batch / parked radiance of live paths
+	return ADYPT_OK;
+}
+
+int ensure_cache_slices(adypt_ctx *c, int extra)
+{
+	if(extra <= c->cache_next_slices) return ADYPT_OK;
+	HIP_TRY(c, hipStreamSynchronize(c->stream)); // the previous batch may still be reading the slices about to be freed
+	if(c->d_cache_next) (void)hipFree(c->d_cache_next); // (they hold nothing between batches)
+	c->d_cache_next = nullptr; c->cache_next_slices = 0;
+	HIP_TRY(c, hipMalloc((void **)&c->d_cache_next, (size_t)extra * (size_t)std::max(c->n_local_px, 64) * sizeof(float4)));
+	c->cache_next_slices = extra;
 	return ADYPT_OK;
 }
 
@@ -469,7 +482,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	{
 		// frames in flight: enough consecutive frames per wavefront pass to keep ~4 M paths in flight (a tile shard of
 		// an 8-GPU run has only 260 k pixels), at most 8; ADYPT_FRAMES_IN_FLIGHT overrides
-		int fif = (int)std::min<size_t>(kMaxFramesInFlight, std::max<size_t>(1, ((size_t)32 << 20) / npx)); // ~32 M paths per wavefront pass: the drain of a launch (its longest rays) is amortised over more work
+		int fif = (int)std::min<size_t>(kMaxFramesInFlight, std::max<size_t>(1, ((size_t)64 << 20) / npx)); // ~64 M paths per wavefront pass: the drain of a launch (its longest rays) is amortised over more work
 		if(const char *ov = getenv("ADYPT_FRAMES_IN_FLIGHT")) fif = std::max(1, std::min(kMaxFramesInFlight, atoi(ov)));
 		TRY_CREATE(alloc_queues(c, fif));
 	}
@@ -500,7 +513,7 @@ void adypt_destroy(adypt_ctx *c)
 	for(EventPair &p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	void *bufs[] = {c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
-					c->d_accum, c->d_cache, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
+					c->d_accum, c->d_cache, c->d_cache_next, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
 					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol};
 	for(void *b : bufs) if(b) (void)hipFree(b);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
@@ -614,11 +627,19 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 		}
 		const int max_bounce = c->params.max_bounce, life = c->params.tmp_lifetime;
 		// Batch = up to frames_in_flight consecutive frames traced as ONE wavefront (frames are independent samples; the
-		// running mean is applied afterwards in frame order, so the result is bit-identical to frame-by-frame).  A frame
-		// that re-traces its primary rays (spp % tmpLifetime == 0) may only be the first frame of a batch.
-		int m = std::min(remaining, c->frames_in_flight);
-		m = std::min(m, life - c->spp % life);
-		const bool retrace = (c->spp % life) == 0;
+		// running mean is applied afterwards in frame order, so the result is bit-identical to frame-by-frame).  A batch
+		// may span several tmpLifetime groups: the frames that re-trace their primary rays (spp % tmpLifetime == 0) run
+		// first, as one primary-only pass, and park their hits in the cache image of their group.
+		const int m = std::min(remaining, c->frames_in_flight);
+		const int first_retrace = (life - c->spp % life) % life;                       // batch index of the first re-tracing frame
+		const int n_retrace = first_retrace < m ? (m - 1 - first_retrace) / life + 1 : 0;
+		const int n_groups = (c->spp + m - 1) / life - c->spp / life + 1;
+		if(m > 1 && n_groups > 1)
+		{
+			int r = ensure_cache_slices(c, n_groups - 1);
+			if(r != ADYPT_OK) return r;
+			fill_pixels(c, &px);
+		}
 		FrameArgs f;
 		fill_frame(c, &f);
 		{
@@ -630,11 +651,11 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 			HIP_TRY(c, hipMemcpyAsync(c->d_sobol, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
 		}
 		HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
-		int use_cache = retrace ? 0 : 1;
-		if(m > 1 && retrace)
+		int use_cache = (m == 1 && n_retrace) ? 0 : 1;
+		if(m > 1 && n_retrace)
 		{
-			// primary-only pass of the re-tracing frame: camera rays -> traversal -> cache image
-			f.n_frames = 1;
+			// primary-only pass of the re-tracing frames: camera rays -> traversal -> cache image of each frame's group
+			f.n_frames = n_retrace; f.frame_first = first_retrace; f.frame_stride = life;
 			QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0]);
 			hipEvent_t *stop = begin_timing(c, 1);
 			hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 1);
@@ -643,10 +664,10 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 			if(r != ADYPT_OK) return r;
 			QueueArgs q2 = queue_args(c, 0, c->d_counters->count[0], c->d_counters->count[1]);
 			stop = begin_timing(c, 1);
-			hipLaunchKernelGGL(k_store_cache, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, q2, px);
+			hipLaunchKernelGGL(k_store_cache, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, q2, px);
 			end_timing(c, stop);
 			HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
-			use_cache = 1;
+			f.frame_first = 0; f.frame_stride = 1;
 		}
 		f.n_frames = m;
 		{
@@ -673,6 +694,9 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 			hipEvent_t *stop = begin_timing(c, 1);
 			hipLaunchKernelGGL(k_resolve, dim3((c->n_local_px + 255) / 256), dim3(256), 0, c->stream, f, sc, px);
 			end_timing(c, stop);
+			// image 1 = the primary hits of the group the last frame belongs to (what frame-by-frame tracing leaves there)
+			if(n_groups > 1)
+				HIP_TRY(c, hipMemcpyAsync(c->d_cache, c->d_cache_next + (size_t)(n_groups - 2) * (size_t)c->n_local_px, (size_t)c->n_local_px * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
 		}
 		HIP_TRY(c, hipGetLastError());
 		c->spp += m;

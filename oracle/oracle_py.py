@@ -80,7 +80,16 @@ def _p(a: Optional[np.ndarray]):
 
 
 def default_threads() -> int:
-    return max(1, len(os.sched_getaffinity(0)))
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box
+    shows all 256 hardware threads in the mask but grants a 16-core share through cpu.max)."""
+    n = max(1, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 # ---------------------------------------------------------------------------------------------------

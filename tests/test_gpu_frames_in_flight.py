@@ -1,6 +1,7 @@
 """-m gpu: several frames in flight per wavefront pass must not change a single bit — frames are independent
-samples, the running mean is applied in frame order, and the frame that re-traces its primary rays
-(spp % tmpLifetime == 0) always starts a batch."""
+samples, the running mean is applied in frame order, and a batch may span several tmpLifetime groups (the frames
+that re-trace their primary rays, spp % tmpLifetime == 0, run a primary-only pass into the cache image of their
+group; image 1 ends up holding the last group's hits, as it does frame by frame)."""
 import numpy as np
 import pytest
 
@@ -18,11 +19,12 @@ def _instance(cache, name, w, h, pt, seed=31):
     return inst
 
 
-@pytest.mark.parametrize("name,w,h,life,spp", [("tiny0", 100, 75, 4, 11), ("tiny0", 96, 64, 16, 20), ("sibenik", 160, 90, 3, 7)])
+@pytest.mark.parametrize("name,w,h,life,spp", [("tiny0", 100, 75, 4, 11), ("tiny0", 96, 64, 16, 20), ("sibenik", 160, 90, 3, 7),
+                                                   ("tiny0", 64, 48, 1, 9), ("tiny0", 72, 40, 2, 37)])
 def test_frames_in_flight_is_bit_invariant(name, w, h, life, spp, scene_cache, sobol_matrices):
     pt_cfg = {"tmpLifetime": life, "maxBounce": 6, "subpixel": 3}
     ref_img, ref_rays = None, None
-    for fif in (1, 2, 5, 8):
+    for fif in (1, 2, 5, 8, 13, 32):
         inst = _instance(scene_cache, name, w, h, pt_cfg)
         p = inst.m_path_tracer
         p.SetFramesInFlight(fif)
