@@ -445,15 +445,15 @@ __global__ __launch_bounds__(kShadeThreads, 6) void k_shade(FrameArgs f, SceneAr
 		}
 		if(!alive) finish_path(f, px, pi, L, ret);
 	}
-	// statistics.  The FetchInfo count is only collected in instrumented runs: even one atomic per wave on a single
-	// word (23 k per launch) costs ~0.27 ms on this chip (~88 same-address atomics/us) — it was 75 % of this kernel.
+	// statistics.  The FetchInfo count is only collected in instrumented runs, one atomic per workgroup: per-wave atomics
+	// on a single word (23 k per launch) cost ~0.27 ms on this chip (~88 same-address atomics/us) — 75 % of this kernel.
 	{
 		const unsigned long long mb = __ballot(bad_mat);
 		if(mb && (threadIdx.x & 63) == 0) atomicAdd(&px.stats->bad_materials, (unsigned long long)__popcll(mb));
-		if(count_stats)
+		if(count_stats) // (kernel argument: uniform branch around the barrier)
 		{
-			const unsigned long long m = __ballot(shaded);
-			if(m && (threadIdx.x & 63) == 0) atomicAdd(&px.stats->shaded, (unsigned long long)__popcll(m));
+			const int n_shaded = __syncthreads_count(shaded);
+			if(n_shaded && threadIdx.x == 0) atomicAdd(&px.stats->shaded, (unsigned long long)n_shaded);
 		}
 	}
 	const uint32_t slot = append_slot(alive, q.count_out + seg * kCursorStride, seg * q.seg_cap);

@@ -143,8 +143,9 @@ def main() -> None:
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
         if world == 1 and (args.scene, args.width, args.height) == ("sponza", 1920, 1080):
-            roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
-            roofline["traffic_source"] = "profiles/r1_pmc_traffic.json (separate rocprofv3 --pmc passes of bench.py --steps 16 --warmup 4); L2 hit rate %.2f" % pmc["TCC_hit_rate"]
+            roofline["traffic"] = round(pmc["traffic_bytes_per_ray"] * st["rays"] / max(1, trace_launches))
+            roofline["traffic_source"] = ("profiles/r1_pmc_traffic.json: %.1f fabric bytes per ray (separate rocprofv3 --pmc passes of bench.py --steps 64 --warmup 0) "
+                                          "x the rays per launch of this run; L2 hit rate %.2f" % (pmc["traffic_bytes_per_ray"], pmc["TCC_hit_rate"]))
     except (OSError, KeyError, ValueError):
         pass
 
