@@ -5,9 +5,10 @@
 
 namespace adypt {
 
-// returns the number of leaves (= triangle references incl. spatial-split duplicates)
+// returns the number of leaves (= triangle references incl. spatial-split duplicates); the node array does not
+// depend on n_threads
 int64_t build_sbvh(const TriRec *tris, int64_t n_tris, const Box &scene_box, const adypt_bvh_params &cfg,
-				   std::vector<BinNode> *nodes, double *ms);
+				   std::vector<BinNode> *nodes, double *ms, int n_threads);
 
 void build_wide_bvh(const std::vector<BinNode> &bin, int64_t leaf_count, const adypt_bvh_params &cfg,
 					std::vector<NodeRec> *nodes, std::vector<int32_t> *tri_indices, double *ms);

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <fstream>
 #include <zlib.h>
+#include <sched.h>
+#include <thread>
 
 using namespace adypt;
 
@@ -147,9 +149,56 @@ void put_attr(std::vector<uint8_t> *o, const char *name, const char *type, const
 
 }  // namespace
 
+extern "C" int adypt_host_get_threads(void);
+// independent items over the host worker threads (contiguous ranges; small jobs stay on the calling thread)
+template <class F> static void parallel_ranges(int64_t n, int64_t min_per_thread, F body)
+{
+	const int threads = (int)std::max<int64_t>(1, std::min<int64_t>(adypt_host_get_threads(), n / std::max<int64_t>(1, min_per_thread)));
+	if(threads <= 1) { body((int64_t)0, n); return; }
+	std::vector<std::thread> pool;
+	for(int t = 1; t < threads; ++t) pool.emplace_back(body, n * t / threads, n * (t + 1) / threads);
+	body((int64_t)0, n / threads);
+	for(std::thread &th : pool) th.join();
+}
+
+
 extern "C" {
 
 // ---------------------------------------------------------------------------------------------------------------
+// worker threads of the BVH build: explicit setting > $ADYPT_BUILD_THREADS > the cores this process may use
+// (affinity mask capped by the cgroup CPU quota)
+static int g_host_threads = 0;
+
+static int available_cores()
+{
+	int n = (int)std::thread::hardware_concurrency();
+	cpu_set_t set;
+	if(sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+	if(FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r"))
+	{
+		char quota[32] = {0};
+		long long period = 0;
+		if(fscanf(f, "%31s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+			n = std::min(n, (int)((atoll(quota) + period / 2) / period));
+		fclose(f);
+	}
+	return std::max(1, std::min(n, 64));
+}
+
+int adypt_host_set_threads(int n)
+{
+	if(n < 0) { set_host_error("adypt_host_set_threads: n must be >= 0 (0 = automatic)"); return ADYPT_E_INVALID; }
+	g_host_threads = n;
+	return ADYPT_OK;
+}
+
+int adypt_host_get_threads(void)
+{
+	if(g_host_threads > 0) return g_host_threads;
+	if(const char *ev = getenv("ADYPT_BUILD_THREADS")) { int n = atoi(ev); if(n > 0) return std::min(n, 256); }
+	return available_cores();
+}
+
 int adypt_bvh_build(const adypt_scene *s, const adypt_bvh_params *p, adypt_bvh **out, adypt_build_info *info)
 {
 	if(!s || !p || !out) { set_host_error("adypt_bvh_build: null argument"); return ADYPT_E_INVALID; }
@@ -159,7 +208,7 @@ int adypt_bvh_build(const adypt_scene *s, const adypt_bvh_params *p, adypt_bvh *
 	{ float lo[3], hi[3]; adypt_scene_aabb(s, lo, hi); box = Box({lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}); }
 	std::vector<BinNode> bin;
 	double sbvh_ms = 0, wide_ms = 0;
-	int64_t leaves = build_sbvh((const TriRec *)tp, nt, box, *p, &bin, &sbvh_ms);
+	int64_t leaves = build_sbvh((const TriRec *)tp, nt, box, *p, &bin, &sbvh_ms, adypt_host_get_threads());
 	adypt_bvh *b = new adypt_bvh();
 	build_wide_bvh(bin, leaves, *p, &b->nodes, &b->tri_indices, &wide_ms);
 	if(info) { info->sbvh_nodes = (int64_t)bin.size(); info->refs = leaves; info->wide_nodes = (int64_t)b->nodes.size(); info->sbvh_ms = sbvh_ms; info->wide_ms = wide_ms; }
@@ -216,7 +265,8 @@ int64_t adypt_bvh_tri_indices(const adypt_bvh *b, const int32_t **idx) { if(idx)
 void adypt_woop_matrices(const void *tris_, const int32_t *tri_indices, int64_t n_refs, float *out)
 {
 	const TriRec *tris = (const TriRec *)tris_;
-	for(int64_t i = 0; i < n_refs; ++i)
+	parallel_ranges(n_refs, 1 << 16, [=](int64_t begin, int64_t end) {
+	for(int64_t i = begin; i < end; ++i)
 	{
 		const TriRec &t = tris[tri_indices[i]];
 		Vec3 e0 = t.p[0] - t.p[2], e1 = t.p[1] - t.p[2];
@@ -228,6 +278,7 @@ void adypt_woop_matrices(const void *tris_, const int32_t *tri_indices, int64_t 
 		o[0] = inv[8]; o[1] = inv[9]; o[2] = inv[10]; o[3] = -inv[11];
 		memcpy(o + 4, inv, 8 * sizeof(float));
 	}
+	});
 }
 
 void adypt_camera_matrices(float fov, float yaw, float pitch, int width, int height, float inv_proj[16], float inv_view[16])

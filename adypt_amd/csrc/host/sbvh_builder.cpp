@@ -7,6 +7,15 @@
 // Structure differs: an explicit task stack instead of recursion (deep trees cannot overflow the call stack) and
 // flat scratch arrays; every float expression keeps the reference's evaluation order (-ffp-contract=off).
 //
+// Parallel build.  What a subtree looks like depends only on (its box, its depth, the ORDER of its
+// references on the stack): the reference builder never touches stack entries below the node it works on.  So the
+// top of the tree is cut into tasks — a task owns a private copy of its references in stack order, performs either
+// ONE split (large nodes: its two children become tasks) or the whole sequential build of its subtree (small nodes)
+// — the tasks run on a thread pool, and the per-task node arrays are stitched together afterwards in the reference's
+// emission order (node, right subtree, left subtree) with the `left` indices rebased.  Every split sees exactly the
+// bytes it would have seen in the sequential build (same std::sort calls on the same sequences), so the node array is
+// bit-identical for any thread count (pinned by tests/test_host_golden.py against the compiled reference).
+//
 // Contract reproduced from the reference:
 //   * references live on one stack; a node owns the last `n` entries; the right child is built first and
 //     lands at parent+1, the left child's index is stored (SBVH.hpp:28-29, SBVHBuilder.cpp:38-41)
@@ -19,6 +28,12 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 namespace adypt {
 namespace {
@@ -43,18 +58,32 @@ public:
 	Builder(const TriRec *tris, int64_t n_tris, const Box &scene_box, const adypt_bvh_params &cfg, std::vector<BinNode> *out)
 		: tris_(tris), n_tris_(n_tris), scene_box_(scene_box), cfg_(cfg), nodes_(*out) {}
 
-	int64_t run()
+	// the references of the whole scene, in triangle order (SBVHBuilder.cpp:52-61)
+	void init_scene_refs()
 	{
-		nodes_.clear();
-		nodes_.reserve((size_t)n_tris_ * 2);
 		refs_.reserve((size_t)n_tris_ * 2);
 		refs_.resize((size_t)n_tris_);
 		for(int64_t i = 0; i < n_tris_; ++i) { refs_[(size_t)i].tri = (int32_t)i; refs_[(size_t)i].box = tris_[i].bounds(); }
+	}
+	std::vector<Ref> &refs() { return refs_; }
+
+	int64_t run()
+	{
+		init_scene_refs();
+		return run_subtree({scene_box_, (int32_t)n_tris_}, 0);
+	}
+
+	// sequential build of the subtree whose references are the last `root.n` entries of refs(); node indices are
+	// local to `out` (root = 0)
+	int64_t run_subtree(const Spec &root, int root_depth)
+	{
+		nodes_.clear();
+		nodes_.reserve((size_t)root.n * 2);
 		min_overlap_ = scene_box_.area() * 1e-5f;
 
 		struct Task { Spec spec; int depth; int32_t patch_parent; };
 		std::vector<Task> todo;
-		todo.push_back({{scene_box_, (int32_t)n_tris_}, 0, -1});
+		todo.push_back({root, root_depth, -1});
 		int64_t leaves = 0;
 		while(!todo.empty())
 		{
@@ -81,6 +110,13 @@ public:
 		}
 		nodes_.shrink_to_fit();
 		return leaves;
+	}
+
+	// one split of the node that owns all of refs(): afterwards refs() = [left->n references | right->n references]
+	void split_once(const Spec &s, int depth, Spec *left, Spec *right)
+	{
+		min_overlap_ = scene_box_.area() * 1e-5f;
+		split(s, depth, left, right);
 	}
 
 private:
@@ -280,14 +316,175 @@ private:
 	}
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// task-parallel driver (see the header comment)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int32_t kSequentialRefs = 8192; // nodes with at most this many references are built whole by one task
+                                          // ($ADYPT_BUILD_GRAIN overrides: the tests cut the tiny reference fixtures too)
+int32_t sequential_refs()
+{
+	if(const char *ev = getenv("ADYPT_BUILD_GRAIN")) { int v = atoi(ev); if(v >= 1) return v; }
+	return kSequentialRefs;
+}
+
+struct SubTask {
+	Spec spec;
+	int depth = 0;
+	std::vector<Ref> refs;        // input: the node's references in stack order (released once consumed)
+	std::vector<BinNode> nodes;   // result of a whole-subtree task (local indices)
+	SubTask *right = nullptr, *left = nullptr; // result of a one-split task
+	int64_t leaves = 0;
+};
+
+class ParallelBuild {
+public:
+	ParallelBuild(const TriRec *tris, int64_t n_tris, const Box &scene_box, const adypt_bvh_params &cfg, int n_threads)
+		: tris_(tris), n_tris_(n_tris), scene_box_(scene_box), cfg_(cfg), n_threads_(n_threads), grain_(sequential_refs()) {}
+
+	int64_t run(std::vector<BinNode> *out)
+	{
+		SubTask *root = new_task();
+		root->spec = {scene_box_, (int32_t)n_tris_};
+		{
+			std::vector<BinNode> dummy;
+			Builder b(tris_, n_tris_, scene_box_, cfg_, &dummy);
+			b.init_scene_refs();
+			root->refs = std::move(b.refs());
+		}
+		push(root);
+		std::vector<std::thread> pool;
+		for(int i = 1; i < n_threads_; ++i) pool.emplace_back([this] { work(); });
+		work();
+		for(std::thread &t : pool) t.join();
+		return stitch(root, out);
+	}
+
+private:
+	const TriRec *tris_;
+	int64_t n_tris_;
+	Box scene_box_;
+	adypt_bvh_params cfg_;
+	int n_threads_;
+	int32_t grain_;
+	std::mutex mu_;
+	std::condition_variable cv_;
+	std::deque<SubTask *> ready_;
+	std::vector<std::unique_ptr<SubTask>> all_;
+	int64_t unfinished_ = 0;
+
+	SubTask *new_task()
+	{
+		std::lock_guard<std::mutex> g(mu_);
+		all_.emplace_back(new SubTask());
+		return all_.back().get();
+	}
+	void push(SubTask *t)
+	{
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			ready_.push_back(t);
+			++unfinished_;
+		}
+		cv_.notify_one();
+	}
+
+	void work()
+	{
+		for(;;)
+		{
+			SubTask *t;
+			{
+				std::unique_lock<std::mutex> g(mu_);
+				cv_.wait(g, [this] { return !ready_.empty() || unfinished_ == 0; });
+				if(ready_.empty()) return;
+				// largest pending nodes first: they spawn the work the other threads are waiting for
+				t = ready_.front();
+				ready_.pop_front();
+			}
+			execute(t);
+			bool all_done;
+			{
+				std::lock_guard<std::mutex> g(mu_);
+				all_done = --unfinished_ == 0;
+			}
+			if(all_done) cv_.notify_all();
+		}
+	}
+
+	void execute(SubTask *t)
+	{
+		Builder b(tris_, n_tris_, scene_box_, cfg_, &t->nodes);
+		b.refs() = std::move(t->refs);
+		if(t->spec.n <= grain_)
+		{
+			t->leaves = b.run_subtree(t->spec, t->depth);
+			return;
+		}
+		Spec ls, rs;
+		b.split_once(t->spec, t->depth, &ls, &rs);
+		std::vector<Ref> &r = b.refs(); // = [left | right] (spatial splits may have added references)
+		SubTask *right = new_task(), *left = new_task();
+		right->spec = rs; right->depth = t->depth + 1;
+		right->refs.assign(r.end() - rs.n, r.end());
+		left->spec = ls; left->depth = t->depth + 1;
+		left->refs.assign(r.end() - rs.n - ls.n, r.end() - rs.n); // what is on top of the stack once the right subtree is done
+		std::vector<Ref>().swap(r);
+		t->right = right; t->left = left;
+		push(right);
+		push(left);
+	}
+
+	// emission order of the reference: node, its whole right subtree (right child = node + 1), then the left subtree
+	int64_t stitch(SubTask *root, std::vector<BinNode> *out)
+	{
+		size_t total = 0;
+		int64_t leaves = 0;
+		for(const auto &t : all_) { total += t->right ? 1 : t->nodes.size(); leaves += t->leaves; }
+		out->clear();
+		out->reserve(total);
+		struct Item { SubTask *t; int32_t patch_parent; };
+		std::vector<Item> todo;
+		todo.push_back({root, -1});
+		while(!todo.empty())
+		{
+			Item it = todo.back();
+			todo.pop_back();
+			const int32_t at = (int32_t)out->size();
+			if(it.patch_parent >= 0) (*out)[(size_t)it.patch_parent].left = at;
+			if(it.t->right)
+			{
+				BinNode n;
+				n.box = it.t->spec.box; n.tri = 0; n.left = -1;
+				out->push_back(n);
+				todo.push_back({it.t->left, at});
+				todo.push_back({it.t->right, -1});
+			}
+			else
+			{
+				for(BinNode n : it.t->nodes)
+				{
+					if(n.left != -1) n.left += at;
+					out->push_back(n);
+				}
+				std::vector<BinNode>().swap(it.t->nodes);
+			}
+		}
+		return leaves;
+	}
+};
+
 }  // namespace
 
 int64_t build_sbvh(const TriRec *tris, int64_t n_tris, const Box &scene_box, const adypt_bvh_params &cfg,
-				   std::vector<BinNode> *nodes, double *ms)
+				   std::vector<BinNode> *nodes, double *ms, int n_threads)
 {
 	auto t0 = std::chrono::steady_clock::now();
 	int64_t leaves = 0;
-	if(n_tris > 0) leaves = Builder(tris, n_tris, scene_box, cfg, nodes).run();
+	if(n_tris > 0)
+	{
+		if(n_threads <= 1 || n_tris <= sequential_refs()) leaves = Builder(tris, n_tris, scene_box, cfg, nodes).run();
+		else leaves = ParallelBuild(tris, n_tris, scene_box, cfg, n_threads).run(nodes);
+	}
 	if(ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	return leaves;
 }

@@ -56,6 +56,11 @@ typedef struct adypt_build_info {
 	int64_t sbvh_nodes, refs, wide_nodes;
 	double sbvh_ms, wide_ms;
 } adypt_build_info;
+/* Worker threads of adypt_bvh_build (the reference's SBVHBuilder is single-threaded,
+ * src/BVH/SBVHBuilder.cpp:49-71).  0 = automatic: $ADYPT_BUILD_THREADS, else the cores the process may use.  The
+ * node and index arrays do not depend on the thread count. */
+int adypt_host_set_threads(int n);
+int adypt_host_get_threads(void);
 /* SBVHBuilder{cfg,&sbvh,scene}.Run(); WideBVHBuilder{cfg,&wbvh,sbvh}.Run(); (src/Instance.cpp:24-26) */
 int adypt_bvh_build(const adypt_scene *s, const adypt_bvh_params *p, adypt_bvh **out, adypt_build_info *info);
 int adypt_bvh_load(const char *path, const adypt_bvh_params *expected, adypt_bvh **out);  /* WideBVH::LoadFromFile */

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+from adypt_amd import _native as N  # noqa: E402
 from adypt_amd import api, scenes
 from oracle import oracle_py as O
 from tests.helpers import GOLDEN, bits, golden_scene
@@ -86,6 +87,31 @@ def test_sobol_shift_camera_host_functions(sobol_matrices):
     for c, r in zip(cams, cref):
         ip, iv = api.camera_matrices(*c)
         assert np.array_equal(bits(ip), bits(r[:16])) and np.array_equal(bits(iv), bits(r[16:]))
+
+
+@pytest.mark.parametrize("name", ["tiny0", "tiny1", "tiny2"])
+def test_parallel_build_equals_reference_for_any_thread_count(name, monkeypatch):
+    """the task-parallel SBVH build (sbvh_builder.cpp) must hand the collapse the very node array the
+    reference's single-threaded builder produces.  ADYPT_BUILD_GRAIN cuts even the tiny reference fixtures into
+    one-split tasks (grain 1 = every inner node is its own task)."""
+    _, idx, nodes, _, _, _ = golden_scene(name)
+    sc = api.Scene()
+    assert sc.LoadFromFile(os.path.join(GOLDEN, name + ".obj"))
+    cfg = api.InstanceConfig()
+    try:
+        for threads, grain in ((1, 0), (2, 1), (3, 7), (8, 64), (5, 500)):
+            if grain:
+                monkeypatch.setenv("ADYPT_BUILD_GRAIN", str(grain))
+            else:
+                monkeypatch.delenv("ADYPT_BUILD_GRAIN", raising=False)
+            assert N.lib.adypt_host_set_threads(threads) == 0 and N.lib.adypt_host_get_threads() == threads
+            b = api.WideBVH()
+            b.Build(sc, cfg.bvh_params())
+            assert b.nodes.tobytes() == nodes.tobytes(), (threads, grain)
+            assert np.array_equal(b.tri_indices, idx), (threads, grain)
+    finally:
+        N.lib.adypt_host_set_threads(0)
+    assert N.lib.adypt_host_set_threads(-1) != 0 and N.lib.adypt_host_get_threads() >= 1
 
 
 @pytest.mark.parametrize("fp16", [False, True])
