@@ -117,6 +117,7 @@ _SIGS = {
     "adypt_scene_from_arrays": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "adypt_host_set_threads": (C.c_int, [C.c_int]),
     "adypt_host_get_threads": (C.c_int, []),
+    "adypt_host_selftest_sort": (C.c_int, [C.c_int64, C.c_uint32, C.c_int, C.c_int, C.c_int64]),
     "adypt_bvh_build": (C.c_int, [C.c_void_p, C.POINTER(BvhParams), C.POINTER(C.c_void_p), C.POINTER(BuildInfo)]),
     "adypt_bvh_load": (C.c_int, [C.c_char_p, C.POINTER(BvhParams), C.POINTER(C.c_void_p)]),
     "adypt_bvh_save": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(BvhParams)]),

@@ -11,6 +11,6 @@ int64_t build_sbvh(const TriRec *tris, int64_t n_tris, const Box &scene_box, con
 				   std::vector<BinNode> *nodes, double *ms, int n_threads);
 
 void build_wide_bvh(const std::vector<BinNode> &bin, int64_t leaf_count, const adypt_bvh_params &cfg,
-					std::vector<NodeRec> *nodes, std::vector<int32_t> *tri_indices, double *ms);
+					std::vector<NodeRec> *nodes, std::vector<int32_t> *tri_indices, double *ms, int n_threads);
 
 }  // namespace adypt

@@ -1,6 +1,7 @@
 // Host-side C entry points around the scene/BVH producers plus the small restated host functions of the tracer's
 // driver: Woop precompute, camera matrices, Sobol stream, per-pixel shift bytes, .bvh cache, OpenEXR output.
 #include "builders.hpp"
+#include "exact_sort.hpp"
 #include "../../../include/adypt_hip.h"
 
 #include <algorithm>
@@ -199,6 +200,58 @@ int adypt_host_get_threads(void)
 	return available_cores();
 }
 
+// exact_sort.hpp against std::sort: same bytes out for the same bytes in
+namespace {
+struct SortRec { float key; int32_t tri; uint32_t payload; };
+bool sort_rec_less(const SortRec &l, const SortRec &r) { return l.key < r.key || (l.key == r.key && l.tri < r.tri); }
+
+// McIlroy's adversary ("A Killer Adversary for Quicksort", 1999) run against std::sort: the keys it freezes make
+// this library's introsort degenerate until it falls back to heap sort
+std::vector<int> killer_keys(int n)
+{
+	std::vector<int> val((size_t)n, n), idx((size_t)n);
+	int solid = 0, candidate = 0;
+	for(int i = 0; i < n; ++i) idx[(size_t)i] = i;
+	std::sort(idx.begin(), idx.end(), [&](int x, int y) {
+		if(val[(size_t)x] == n && val[(size_t)y] == n) { if(x == candidate) val[(size_t)x] = solid++; else val[(size_t)y] = solid++; }
+		if(val[(size_t)x] == n) candidate = x; else if(val[(size_t)y] == n) candidate = y;
+		return val[(size_t)x] < val[(size_t)y];
+	});
+	return val;
+}
+}  // namespace
+
+int adypt_host_selftest_sort(int64_t n, uint32_t seed, int pattern, int threads, int64_t min_task)
+{
+	if(n < 0 || n > ((int64_t)1 << 28) || threads < 1 || min_task < 1) { set_host_error("adypt_host_selftest_sort: bad argument"); return ADYPT_E_INVALID; }
+	std::vector<SortRec> a((size_t)n);
+	uint32_t x = seed * 2654435761u + 12345u;
+	auto rnd = [&] { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+	std::vector<int> killer;
+	if(pattern == 5) killer = killer_keys((int)n);
+	for(int64_t i = 0; i < n; ++i)
+	{
+		SortRec &r = a[(size_t)i];
+		r.payload = (uint32_t)i;
+		switch(pattern)
+		{
+		case 0: r.key = (float)(rnd() >> 8); r.tri = (int32_t)(rnd() & 0xffff); break;               // mostly distinct
+		case 1: r.key = (float)(rnd() % (uint32_t)std::max<int64_t>(1, n / 64)); r.tri = (int32_t)(rnd() & 3); break; // heavy ties
+		case 2: r.key = (float)(i / 3); r.tri = 7; break;                                              // sorted, tied triples
+		case 3: r.key = (float)((n - i) / 2); r.tri = (int32_t)(i & 1); break;                         // reversed
+		case 4: r.key = 1.0f; r.tri = 0; break;                                                        // all equal
+		case 5: r.key = (float)killer[(size_t)i]; r.tri = 0; break;                                    // quicksort killer
+		default: set_host_error("adypt_host_selftest_sort: pattern must be 0..5"); return ADYPT_E_INVALID;
+		}
+	}
+	std::vector<SortRec> b = a;
+	std::sort(a.begin(), a.end(), sort_rec_less);
+	bool (*less)(const SortRec &, const SortRec &) = sort_rec_less;
+	ExactSort<SortRec, decltype(less)>(less, threads, min_task).sort(b.data(), b.data() + b.size());
+	if(n && memcmp(a.data(), b.data(), (size_t)n * sizeof(SortRec)) != 0) { set_host_error("adypt_host_selftest_sort: permutation differs from std::sort"); return ADYPT_E_INVALID; }
+	return ADYPT_OK;
+}
+
 int adypt_bvh_build(const adypt_scene *s, const adypt_bvh_params *p, adypt_bvh **out, adypt_build_info *info)
 {
 	if(!s || !p || !out) { set_host_error("adypt_bvh_build: null argument"); return ADYPT_E_INVALID; }
@@ -210,7 +263,7 @@ int adypt_bvh_build(const adypt_scene *s, const adypt_bvh_params *p, adypt_bvh *
 	double sbvh_ms = 0, wide_ms = 0;
 	int64_t leaves = build_sbvh((const TriRec *)tp, nt, box, *p, &bin, &sbvh_ms, adypt_host_get_threads());
 	adypt_bvh *b = new adypt_bvh();
-	build_wide_bvh(bin, leaves, *p, &b->nodes, &b->tri_indices, &wide_ms);
+	build_wide_bvh(bin, leaves, *p, &b->nodes, &b->tri_indices, &wide_ms, adypt_host_get_threads());
 	if(info) { info->sbvh_nodes = (int64_t)bin.size(); info->refs = leaves; info->wide_nodes = (int64_t)b->nodes.size(); info->sbvh_ms = sbvh_ms; info->wide_ms = wide_ms; }
 	*out = b;
 	return ADYPT_OK;

@@ -25,9 +25,11 @@
 //     32 bins per axis with exact triangle clipping (hpp:136-228), unsplit-left/unsplit-right/duplicate
 //     decision per straddling reference (hpp:230-306)
 #include "builders.hpp"
+#include "exact_sort.hpp"
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
 #include <deque>
@@ -53,6 +55,12 @@ template <int D> bool ref_less(const Ref &l, const Ref &r)
 	return lc < rc || (lc == rc && l.tri < r.tri);
 }
 
+inline std::vector<Box> &sweep_scratch()
+{
+	static thread_local std::vector<Box> scratch;
+	return scratch;
+}
+
 class Builder {
 public:
 	Builder(const TriRec *tris, int64_t n_tris, const Box &scene_box, const adypt_bvh_params &cfg, std::vector<BinNode> *out)
@@ -66,6 +74,7 @@ public:
 		for(int64_t i = 0; i < n_tris_; ++i) { refs_[(size_t)i].tri = (int32_t)i; refs_[(size_t)i].box = tris_[i].bounds(); }
 	}
 	std::vector<Ref> &refs() { return refs_; }
+	void set_sort_threads(int threads, int64_t min_task) { sort_threads_ = threads; sort_min_task_ = min_task; }
 
 	int64_t run()
 	{
@@ -126,9 +135,11 @@ private:
 	adypt_bvh_params cfg_;
 	std::vector<BinNode> &nodes_;
 	std::vector<Ref> refs_;
-	std::vector<Box> right_boxes_;
+	std::vector<Box> &right_boxes_ = sweep_scratch(); // per thread, kept across tasks: fresh pages are expensive to touch
 	Bin bins_[kBins];
 	float min_overlap_ = 0.0f;
+	int sort_threads_ = 1;
+	int64_t sort_min_task_ = 1 << 15;
 
 	float tri_cost(int count) const { return cfg_.triangle_sah * count; }
 	float node_cost(int count) const { return cfg_.node_sah * count; }
@@ -137,6 +148,9 @@ private:
 	void sort_refs(const Spec &s, int dim)
 	{
 		Ref *b = refs_.data() + first_ref(s), *e = refs_.data() + refs_.size();
+		bool (*less)(const Ref &, const Ref &) = dim == 0 ? ref_less<0> : dim == 1 ? ref_less<1> : ref_less<2>;
+		// large nodes of the task-parallel build: the same permutation as std::sort, computed on several threads
+		if(sort_threads_ > 1 && e - b >= 2 * sort_min_task_) { ExactSort<Ref, decltype(less)>(less, sort_threads_, sort_min_task_).sort(b, e); return; }
 		if(dim == 0) std::sort(b, e, ref_less<0>);
 		else if(dim == 1) std::sort(b, e, ref_less<1>);
 		else std::sort(b, e, ref_less<2>);
@@ -288,11 +302,18 @@ private:
 
 	void split(const Spec &s, int depth, Spec *left, Spec *right)
 	{
+#ifdef ADYPT_BUILD_TIMING
+		auto T0 = std::chrono::steady_clock::now();
+		auto lap = [&](const char *what) { if(s.n > 500000) { auto T1 = std::chrono::steady_clock::now(); fprintf(stderr, "[split n=%d d=%d thr=%d] %s %.2f s\n", s.n, depth, sort_threads_, what, std::chrono::duration<double>(T1 - T0).count()); T0 = T1; } };
+#else
+		auto lap = [](const char *) {};
+#endif
 		float node_sah = s.box.area() * node_cost(2);
 		ObjSplit os;
 		object_split_axis(s, 0, node_sah, &os);
 		object_split_axis(s, 1, node_sah, &os);
 		object_split_axis(s, 2, node_sah, &os);
+		lap("object split (3 sorts + sweeps)");
 		SpatSplit ss;
 		if(depth <= cfg_.max_spatial_depth)
 		{
@@ -305,11 +326,14 @@ private:
 				spatial_split_axis(s, 2, node_sah, &ss);
 			}
 		}
+		lap("spatial bins");
 		left->n = right->n = 0;
 		if(ss.sah < os.sah) do_spatial_split(s, ss, left, right);
+		lap("do_spatial_split");
 		if(left->n == 0 || right->n == 0)
 		{
 			sort_refs(s, os.dim);
+			lap("final sort");
 			left->n = os.left_n; left->box = os.left;
 			right->n = s.n - os.left_n; right->box = os.right;
 		}
@@ -326,6 +350,11 @@ int32_t sequential_refs()
 	if(const char *ev = getenv("ADYPT_BUILD_GRAIN")) { int v = atoi(ev); if(v >= 1) return v; }
 	return kSequentialRefs;
 }
+int64_t sort_min_task()  // smallest range the parallel sort hands to another thread ($ADYPT_BUILD_SORT_GRAIN: tests)
+{
+	if(const char *ev = getenv("ADYPT_BUILD_SORT_GRAIN")) { int v = atoi(ev); if(v >= 1) return v; }
+	return 1 << 15;
+}
 
 struct SubTask {
 	Spec spec;
@@ -339,7 +368,7 @@ struct SubTask {
 class ParallelBuild {
 public:
 	ParallelBuild(const TriRec *tris, int64_t n_tris, const Box &scene_box, const adypt_bvh_params &cfg, int n_threads)
-		: tris_(tris), n_tris_(n_tris), scene_box_(scene_box), cfg_(cfg), n_threads_(n_threads), grain_(sequential_refs()) {}
+		: tris_(tris), n_tris_(n_tris), scene_box_(scene_box), cfg_(cfg), n_threads_(n_threads), grain_(sequential_refs()), sort_min_task_(sort_min_task()) {}
 
 	int64_t run(std::vector<BinNode> *out)
 	{
@@ -366,11 +395,36 @@ private:
 	adypt_bvh_params cfg_;
 	int n_threads_;
 	int32_t grain_;
+	int64_t sort_min_task_;
 	std::mutex mu_;
 	std::condition_variable cv_;
 	std::deque<SubTask *> ready_;
 	std::vector<std::unique_ptr<SubTask>> all_;
 	int64_t unfinished_ = 0;
+
+	// Reference buffers are recycled between tasks: a finished task's vector (capacity intact) serves a later right
+	// child.  First-touching fresh pages costs more than the copy itself on the virtualised hosts this runs on.
+	std::vector<std::vector<Ref>> buffers_;
+	std::vector<Ref> acquire(size_t n)
+	{
+		std::vector<Ref> v;
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			size_t best = buffers_.size();
+			for(size_t i = 0; i < buffers_.size(); ++i)
+				if(buffers_[i].capacity() >= n && (best == buffers_.size() || buffers_[i].capacity() < buffers_[best].capacity())) best = i;
+			if(best != buffers_.size()) { v = std::move(buffers_[best]); buffers_[best] = std::move(buffers_.back()); buffers_.pop_back(); }
+		}
+		v.clear();
+		return v;
+	}
+	void release(std::vector<Ref> &&v)
+	{
+		if(v.capacity() < 1024) return;
+		v.clear();
+		std::lock_guard<std::mutex> g(mu_);
+		buffers_.push_back(std::move(v));
+	}
 
 	SubTask *new_task()
 	{
@@ -418,17 +472,25 @@ private:
 		if(t->spec.n <= grain_)
 		{
 			t->leaves = b.run_subtree(t->spec, t->depth);
+			release(std::move(b.refs()));
 			return;
 		}
+		// the few large nodes at the top of the tree are the critical path: their sorts get a share of the threads
+		// proportional to the node's share of the scene (the nodes of one level together own about all references)
+		b.set_sort_threads((int)std::max<int64_t>(1, std::min<int64_t>(n_threads_, ((int64_t)n_threads_ * t->spec.n + n_tris_ / 2) / n_tris_)), sort_min_task_);
 		Spec ls, rs;
 		b.split_once(t->spec, t->depth, &ls, &rs);
 		std::vector<Ref> &r = b.refs(); // = [left | right] (spatial splits may have added references)
 		SubTask *right = new_task(), *left = new_task();
 		right->spec = rs; right->depth = t->depth + 1;
+		right->refs = acquire((size_t)rs.n + (size_t)rs.n / 4);
+		right->refs.reserve((size_t)rs.n + (size_t)rs.n / 4);
 		right->refs.assign(r.end() - rs.n, r.end());
 		left->spec = ls; left->depth = t->depth + 1;
-		left->refs.assign(r.end() - rs.n - ls.n, r.end() - rs.n); // what is on top of the stack once the right subtree is done
-		std::vector<Ref>().swap(r);
+		// the left child owns what is on top of the stack once the right subtree is done; it keeps the parent's buffer
+		if(r.size() != (size_t)ls.n + (size_t)rs.n) r.erase(r.begin(), r.end() - rs.n - ls.n);
+		r.resize((size_t)ls.n);
+		left->refs = std::move(r);
 		t->right = right; t->left = left;
 		push(right);
 		push(left);

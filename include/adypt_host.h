@@ -61,6 +61,11 @@ typedef struct adypt_build_info {
  * node and index arrays do not depend on the thread count. */
 int adypt_host_set_threads(int n);
 int adypt_host_get_threads(void);
+/* Self-test of the multi-threaded sort the parallel build uses for its largest nodes (csrc/host/exact_sort.hpp): it
+ * must return the very permutation std::sort returns (ties between the halves of a split triangle make the
+ * permutation part of the node array).  pattern 0 random, 1 heavy ties, 2 sorted, 3 reversed, 4 all equal,
+ * 5 quicksort killer (reaches the heap-sort fallback).  Returns 0 when both sorts agree byte for byte. */
+int adypt_host_selftest_sort(int64_t n, uint32_t seed, int pattern, int threads, int64_t min_task);
 /* SBVHBuilder{cfg,&sbvh,scene}.Run(); WideBVHBuilder{cfg,&wbvh,sbvh}.Run(); (src/Instance.cpp:24-26) */
 int adypt_bvh_build(const adypt_scene *s, const adypt_bvh_params *p, adypt_bvh **out, adypt_build_info *info);
 int adypt_bvh_load(const char *path, const adypt_bvh_params *expected, adypt_bvh **out);  /* WideBVH::LoadFromFile */

@@ -99,19 +99,31 @@ def test_parallel_build_equals_reference_for_any_thread_count(name, monkeypatch)
     assert sc.LoadFromFile(os.path.join(GOLDEN, name + ".obj"))
     cfg = api.InstanceConfig()
     try:
-        for threads, grain in ((1, 0), (2, 1), (3, 7), (8, 64), (5, 500)):
-            if grain:
-                monkeypatch.setenv("ADYPT_BUILD_GRAIN", str(grain))
-            else:
-                monkeypatch.delenv("ADYPT_BUILD_GRAIN", raising=False)
+        for threads, grain, sort_grain in ((1, 0, 0), (2, 1, 0), (3, 7, 32), (8, 64, 40), (5, 500, 100), (8, 2000, 32)):
+            for var, val in (("ADYPT_BUILD_GRAIN", grain), ("ADYPT_BUILD_SORT_GRAIN", sort_grain)):
+                if val:
+                    monkeypatch.setenv(var, str(val))  # sort grain: the largest nodes use the multi-threaded exact sort
+                else:
+                    monkeypatch.delenv(var, raising=False)
             assert N.lib.adypt_host_set_threads(threads) == 0 and N.lib.adypt_host_get_threads() == threads
             b = api.WideBVH()
             b.Build(sc, cfg.bvh_params())
-            assert b.nodes.tobytes() == nodes.tobytes(), (threads, grain)
-            assert np.array_equal(b.tri_indices, idx), (threads, grain)
+            assert b.nodes.tobytes() == nodes.tobytes(), (threads, grain, sort_grain)
+            assert np.array_equal(b.tri_indices, idx), (threads, grain, sort_grain)
     finally:
         N.lib.adypt_host_set_threads(0)
     assert N.lib.adypt_host_set_threads(-1) != 0 and N.lib.adypt_host_get_threads() >= 1
+
+
+@pytest.mark.parametrize("pattern", range(6))
+def test_parallel_sort_returns_the_permutation_of_std_sort(pattern):
+    """exact_sort.hpp restates the library's introsort so that it can run on several threads; ties make the permutation
+    part of the BVH (see the header).  Patterns: random, heavy ties, sorted, reversed, all equal, quicksort killer."""
+    for n, threads, min_task in ((0, 2, 32), (1, 2, 32), (2, 2, 32), (16, 2, 32), (17, 3, 32), (1000, 4, 32), (65536, 8, 32),
+                                 (100001, 1, 32), (250000, 5, 1000), (600000, 8, 1 << 15)):
+        if pattern == 5 and n > 250000:
+            continue
+        assert N.lib.adypt_host_selftest_sort(n, 11 + pattern, pattern, threads, min_task) == 0, (pattern, n, threads, N.lib.adypt_host_last_error())
 
 
 @pytest.mark.parametrize("fp16", [False, True])

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--scene", default="sanmiguel")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--cache", default="/tmp/adypt_large")
     ap.add_argument("--no-gpu", action="store_true", help="stop after the host build (no device needed)")
     ap.add_argument("--out", default="")
@@ -42,6 +42,10 @@ def main():
     bvh = api.WideBVH()
     bvh.Build(sc, cfg.bvh_params())
     rep["bvh_build_s"] = round(time.time() - t, 2)
+    from adypt_amd import _native as N
+    rep["build_threads"] = int(N.lib.adypt_host_get_threads())
+    rep["sbvh_s"] = round(bvh.build_info.sbvh_ms / 1e3, 2)
+    rep["wide_s"] = round(bvh.build_info.wide_ms / 1e3, 2)
     rep["wide_nodes"] = int(len(bvh.GetNodes()) // 80)
     rep["refs"] = int(len(bvh.GetTriIndices()))
     if not a.no_gpu:
@@ -84,6 +88,23 @@ def main():
         dt = time.time() - t
         rep["gpu_ms_per_frame"] = round(dt / a.frames * 1e3, 3)
         rep["gpu_mrays_per_s"] = round(pt.GetStats()["rays"] / dt / 1e6, 1)
+        rep["frames_in_flight"] = pt.GetFramesInFlight()
+        # kernel times (HIP events) and the exact byte census of the same frames -> algorithmic GB/s of the traversal
+        pt.Reset(); pt.SetInstrumentation(timing=True); pt.Trace(True, 16); pt.ResetStats()
+        pt.Trace(True, a.frames)
+        ts = pt.GetStats()
+        pt.Reset(); pt.SetInstrumentation(timing=False, counters=True); pt.Trace(True, 16); pt.ResetStats()
+        pt.Trace(True, a.frames)
+        cs = pt.GetStats()
+        alg = 80 * cs["nodes_visited"] + 48 * cs["tris_tested"] + 4 * cs["hits"] + 48 * cs["rays"]
+        rep["trace_ms_per_frame"] = round(ts["trace_ms"] / a.frames, 3)
+        rep["shade_ms_per_frame"] = round(ts["shade_ms"] / a.frames, 3)
+        rep["trace_kernel_mrays_per_s"] = round(ts["rays"] / ts["trace_ms"] / 1e3, 1)
+        rep["nodes_per_ray"] = round(cs["nodes_visited"] / cs["rays"], 2)
+        rep["tris_per_ray"] = round(cs["tris_tested"] / cs["rays"], 2)
+        rep["alg_bytes_per_ray"] = round(alg / cs["rays"], 1)
+        rep["trace_alg_GBs"] = round(alg / (ts["trace_ms"] * 1e-3) / 1e9, 1)
+        rep["bvh_MB"] = round((len(bvh.nodes) + len(bvh.tri_indices) * 52) / 1e6, 1)  # nodes (bytes) + Woop 48 B + index 4 B per reference
     line = json.dumps(rep)
     print(line)
     if a.out:
