@@ -312,9 +312,13 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				{
 					const uint32_t meta4 = g ? n1.w : n1.z;
 					const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-					// per-byte select mask for octinv (<= 7): (b << 3) - b = 7 for inner bytes, no multiply, no cross-byte borrow
+					// per-byte select mask for octinv (<= 7): 0x07 in the inner bytes = b | b << 1 | b << 2.  Written as two
+					// v_lshl_or_b32: any C spelling of it is canonicalised by the compiler into the quarter-rate v_mul_lo_u32 (x 7)
 					const uint32_t inner1 = is_inner4 >> 4;
-					const uint32_t bit_index4 = (meta4 ^ (octinv4 & ((inner1 << 3) - inner1))) & 0x1f1f1f1fu;
+					uint32_t inner3, inner7;
+					asm("v_lshl_or_b32 %0, %1, 1, %1" : "=v"(inner3) : "v"(inner1));
+					asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(inner7) : "v"(inner1), "v"(inner3));
+					const uint32_t bit_index4 = (meta4 ^ (octinv4 & inner7)) & 0x1f1f1f1fu;
 					const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
 					const uint32_t qlox = g ? n2.y : n2.x, qloy = g ? n2.w : n2.z, qloz = g ? n3.y : n3.x;
 					const uint32_t qhix = g ? n3.w : n3.z, qhiy = g ? n4.y : n4.x, qhiz = g ? n4.w : n4.z;
