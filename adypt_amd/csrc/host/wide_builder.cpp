@@ -335,7 +335,10 @@ private:
 	void emit(int w, int s, std::vector<std::pair<int, int>> *todo, Cursor *cur_pos)
 	{
 		int child[8], n_child = 0;
-		gather_children(s, 1, &n_child, child);
+		// a one-triangle scene has a leaf as its binary root (the reference's collapse dereferences its missing children and
+		// crashes): the root wide node then gets that leaf as its only child
+		if(is_leaf(s)) child[n_child++] = s;
+		else gather_children(s, 1, &n_child, child);
 		const Box &box = bin_[(size_t)s].box;
 		Vec3 cell;
 		{

@@ -1,0 +1,95 @@
+"""-m gpu: degenerate scenes through the HIP kernels vs the oracle, bit for bit.  Zero-area triangles (collinear,
+collapsed to a point) have a singular Woop matrix — glm::inverse divides by a zero determinant, so their 48-byte
+records hold inf/NaN (OglScene.cpp:93-116 does not guard it); the traversal must carry those through its comparisons
+exactly like the restatement does.  Also: a one-triangle scene (the reference's collapse crashes; the product builds a
+one-child root), rays that start on / run inside triangle planes, empty ray batches, 1x1 and odd-sized images."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from adypt_amd import api  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+from tests.helpers import GOLDEN, bits  # noqa: E402
+
+
+def _tracer(obj_path, w, h, stack=24):
+    sc = api.Scene()
+    assert sc.LoadFromFile(obj_path)
+    cfg = api.InstanceConfig()
+    b = api.WideBVH()
+    b.Build(sc, cfg.bvh_params())
+    hs = api.HipScene()
+    hs.Initialize(sc, b)
+    p = cfg.pt_params(77)
+    p.stack_size, p.max_bounce, p.subpixel, p.tmp_lifetime = stack, 4, 2, 3
+    p.sun[:] = [3.0, 2.0, 1.0]
+    pt = api.HipPathTracer()
+    pt.Initialize(p, hs, w, h)
+    return sc, b, pt, p
+
+
+def _rays(n, seed):
+    rs = np.random.RandomState(seed)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, :3] = rs.uniform(-2, 12, size=(n, 3)) * np.array([1, 0.2, 0.2], np.float32)
+    rays[:, 3] = 1e-4
+    rays[:, 4:7] = rs.normal(size=(n, 3))
+    k = n // 8
+    rays[:k, 6] = 0.0                      # inside the z = 0 plane of the flat / degenerate cases
+    rays[k:2 * k, 5:7] = 0.0               # along the x axis: through collinear triangles
+    rays[2 * k:3 * k, :3] = 0.0            # origin on the shared vertex / the collapsed point
+    rays[3 * k:4 * k, 4:7] = [0.0, 0.0, -1.0]
+    return rays
+
+
+@pytest.mark.parametrize("name", ["rand_1", "rand_2", "rand_9", "degenerate_5", "degenerate_9", "flat_9", "point_4"])
+def test_degenerate_scene_traversal_and_frames_match_oracle(name, tmp_path, sobol_matrices):
+    c = json.load(open(os.path.join(GOLDEN, "edge_cases.json")))[name]
+    obj = tmp_path / (name + ".obj")
+    obj.write_text(c["obj"])
+    w, h = 37, 23
+    sc, b, pt, p = _tracer(str(obj), w, h)
+    osc = O.Scene(b.nodes, b.tri_indices, sc.triangles, sc.materials)
+    rays = _rays(4096, 3)
+    assert pt.TraceRays(rays, with_stats=True).tobytes() == O.trace(osc, rays, p.stack_size).tobytes()
+    assert pt.TraceRays(rays[:0], with_stats=True).shape[0] == 0            # empty batch
+    ip, iv = api.camera_matrices(60.0, 0.0, -5.0, w, h)
+    pos = [4.0, 0.3, 6.0]
+    pt.SetCamera(ip, iv, pos)
+    P = O.make_params(w, h, pos, ip, iv, stack_size=p.stack_size, max_bounce=p.max_bounce, subpixel=p.subpixel,
+                      tmp_life=p.tmp_lifetime, tmin=p.ray_tmin, clamp=p.clamp, sun=list(p.sun))
+    pt.Trace(False)
+    rgba, _, _ = O.primary_frame(osc, P, 0)
+    assert np.array_equal(bits(pt.ReadResult()), bits(rgba[..., :3]))
+    pt.SetInstrumentation(counters=True)
+    pt.ResetStats()
+    pt.Trace(True, 7)                                                        # crosses two tmpLifetime groups
+    st = O.PathTracerState(w, h)
+    ost = O.pt_frames(osc, P, O.shift_bytes(77, w, h), sobol_matrices, st, 7).as_dict()
+    assert np.array_equal(bits(pt.ReadResult()), bits(st.accum[..., :3]))
+    g = pt.GetStats()
+    assert (g["rays"], g["nodes_visited"], g["tris_tested"], g["hits"]) == (ost["rays"], ost["nodes"], ost["tris"], ost["hits"])
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 1), (1, 3), (33, 31), (65, 2)])
+def test_minimal_and_odd_image_sizes(w, h, tmp_path, sobol_matrices):
+    c = json.load(open(os.path.join(GOLDEN, "edge_cases.json")))["rand_25"]
+    obj = tmp_path / "s.obj"
+    obj.write_text(c["obj"])
+    sc, b, pt, p = _tracer(str(obj), w, h)
+    osc = O.Scene(b.nodes, b.tri_indices, sc.triangles, sc.materials)
+    ip, iv = api.camera_matrices(70.0, 10.0, 0.0, w, h)
+    pos = [0.1, 0.0, 3.0]
+    pt.SetCamera(ip, iv, pos)
+    P = O.make_params(w, h, pos, ip, iv, stack_size=p.stack_size, max_bounce=p.max_bounce, subpixel=p.subpixel,
+                      tmp_life=p.tmp_lifetime, tmin=p.ray_tmin, clamp=p.clamp, sun=list(p.sun))
+    pt.Trace(True, 5)
+    st = O.PathTracerState(w, h)
+    O.pt_frames(osc, P, O.shift_bytes(77, w, h), sobol_matrices, st, 5)
+    img = pt.ReadResult()
+    assert img.shape == (h, w, 3)
+    assert np.array_equal(bits(img), bits(st.accum[..., :3]))
