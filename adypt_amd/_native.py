@@ -97,6 +97,7 @@ _SIGS = {
     "adypt_reset_stats": (C.c_int, [C.c_void_p]),
     "adypt_get_wave_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "adypt_local_pixel_count": (C.c_int64, [C.c_void_p]),
+    "adypt_read_display": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adypt_local_radiance_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "adypt_copy_local_radiance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "adypt_shard_block_count": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -129,6 +130,7 @@ _SIGS = {
     "adypt_sobol_points": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "adypt_shift_bytes": (None, [C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "adypt_save_exr": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "adypt_save_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
     "adypt_load_exr": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "adypt_free": (None, [C.c_void_p]),
 }

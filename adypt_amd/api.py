@@ -226,6 +226,13 @@ def save_exr(path: str, rgb: np.ndarray, save_as_fp16: bool = False) -> None:
     N.check_host(N.lib.adypt_save_exr(path.encode(), rgb.ctypes.data, w, h, 1 if save_as_fp16 else 0))
 
 
+def save_png(path: str, rgba8: np.ndarray) -> None:
+    rgba8 = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    h, w = rgba8.shape[:2]
+    assert rgba8.shape == (h, w, 4)
+    N.check_host(N.lib.adypt_save_png(path.encode(), rgba8.ctypes.data, w, h))
+
+
 def load_exr(path: str) -> np.ndarray:
     p = C.c_void_p()
     w = C.c_int()
@@ -339,6 +346,15 @@ class HipPathTracer:
         rgb = np.zeros((self.height, self.width, 3), dtype=np.float32)
         N.check(N.lib.adypt_read_radiance(self._ctx, rgb.ctypes.data), self._ctx)
         return rgb
+
+    def ReadDisplay(self) -> np.ndarray:
+        """What OglPathTracer::DrawScreen puts on screen (shaders/screen.glsl:15-21): H x W x 4 uint8."""
+        rgba = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        N.check(N.lib.adypt_read_display(self._ctx, rgba.ctypes.data), self._ctx)
+        return rgba
+
+    def SavePreview(self, filename: str) -> None:
+        save_png(filename, self.ReadDisplay())
 
     def ReadHits(self) -> Tuple[np.ndarray, np.ndarray]:
         tri = np.full((self.height, self.width), -1, dtype=np.int32)

@@ -2,7 +2,8 @@
 //   Instance::InitializeFromFile / Initialize (src/Instance.cpp:10-42,59-69) -> N x Trace(true) -> SaveResult
 //   (src/Tracer/OglPathTracer.cpp:199-212).  The interactive window / ImGui front-end is out of scope.
 //
-//   adypt_hip scene.config [--spp N] [--out result.exr] [--fp16] [--primary TYPE] [--seed S] [--device D]
+//   adypt_hip scene.config [--spp N] [--out result.exr] [--fp16] [--primary TYPE] [--preview file.png] [--seed S] [--device D]
+//   --preview: what the reference shows in its window (shaders/screen.glsl), as PNG
 #include "adypt_hip.h"
 #include "adypt_host.h"
 
@@ -20,15 +21,16 @@ static double now_ms()
 
 int main(int argc, char **argv)
 {
-	if(argc < 2) { fprintf(stderr, "usage: %s scene.config [--spp N] [--out file.exr] [--fp16] [--primary TYPE] [--seed S] [--device D]\n", argv[0]); return 2; }
+	if(argc < 2) { fprintf(stderr, "usage: %s scene.config [--spp N] [--out file.exr] [--fp16] [--primary TYPE] [--preview file.png] [--seed S] [--device D]\n", argv[0]); return 2; }
 	int spp = 64, fp16 = 0, primary = -1, device = 0;
 	unsigned seed = 12345;
-	std::string out = "result.exr";
+	std::string out = "result.exr", preview;
 	for(int i = 2; i < argc; ++i)
 	{
 		std::string a = argv[i];
 		if(a == "--spp" && i + 1 < argc) spp = atoi(argv[++i]);
 		else if(a == "--out" && i + 1 < argc) out = argv[++i];
+		else if(a == "--preview" && i + 1 < argc) preview = argv[++i];
 		else if(a == "--fp16") fp16 = 1;
 		else if(a == "--primary" && i + 1 < argc) primary = atoi(argv[++i]);
 		else if(a == "--seed" && i + 1 < argc) seed = (unsigned)strtoul(argv[++i], nullptr, 10);
@@ -85,6 +87,13 @@ int main(int argc, char **argv)
 	if(adypt_read_radiance(ctx, rgb.data()) != ADYPT_OK) { fprintf(stderr, "[TRACER]Err: %s\n", adypt_last_error(ctx)); return 1; }
 	if(adypt_save_exr(out.c_str(), rgb.data(), cfg.width, cfg.height, fp16) != ADYPT_OK) { fprintf(stderr, "[PT]ERR: %s\n", adypt_host_last_error()); return 1; }
 	printf("[PT]INFO: Saved image to %s\n", out.c_str());
+	if(!preview.empty())
+	{
+		std::vector<uint8_t> rgba8((size_t)cfg.width * cfg.height * 4, 0);
+		if(adypt_read_display(ctx, rgba8.data()) != ADYPT_OK) { fprintf(stderr, "[TRACER]Err: %s\n", adypt_last_error(ctx)); return 1; }
+		if(adypt_save_png(preview.c_str(), rgba8.data(), cfg.width, cfg.height) != ADYPT_OK) { fprintf(stderr, "[PT]ERR: %s\n", adypt_host_last_error()); return 1; }
+		printf("[PT]INFO: Saved preview to %s\n", preview.c_str());
+	}
 	adypt_destroy(ctx);
 	adypt_bvh_free(bvh);
 	adypt_scene_free(scene);

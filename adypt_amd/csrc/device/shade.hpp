@@ -511,6 +511,35 @@ __global__ __launch_bounds__(kShadeThreads) void k_viewer(FrameArgs f, SceneArgs
 	px.accum[L] = make_float4(color.x, color.y, color.z, 1.0f);
 }
 
+// screen.glsl main (:15-21): what the reference's full-screen quad shows for the result image — gamma 1/2.2 for the
+// colour viewers and the path-traced radiance (uType <= 3), normalize(v) * 0.5 + 0.5 for the normal / position viewers —
+// quantised like a GL RGBA8 UNORM colour buffer: round(clamp(c, 0, 1) * 255), NaN -> 0.  Canonical arithmetic: the
+// exponent is the binary32 quotient 1.0f / 2.2f, pow is canon_pow.  One RGBA8 word per local pixel (R in the low byte).
+__device__ __forceinline__ uint32_t unorm8(float c)
+{
+	if(!(c > 0.0f)) return 0u; // also NaN
+	if(c >= 1.0f) return 255u;
+	return (uint32_t)floorf(fmaf(c, 255.0f, 0.5f));
+}
+__global__ __launch_bounds__(256) void k_display(const float4 *accum, int n_local_px, int viewer_type, uint32_t *out)
+{
+	const int L = blockIdx.x * blockDim.x + threadIdx.x;
+	if(L >= n_local_px) return;
+	const float4 v = accum[L];
+	F3 c;
+	if(viewer_type <= 3)
+	{
+		const float g = 1.0f / 2.2f;
+		c = f3(canon_pow(v.x, g), canon_pow(v.y, g), canon_pow(v.z, g));
+	}
+	else
+	{
+		const F3 n = normalize3(f3(v.x, v.y, v.z));
+		c = f3(n.x * 0.5f + 0.5f, n.y * 0.5f + 0.5f, n.z * 0.5f + 0.5f);
+	}
+	out[L] = unorm8(c.x) | unorm8(c.y) << 8 | unorm8(c.z) << 16 | 0xff000000u;
+}
+
 // compact block-major RGBA (one rank's buffer) -> rows of the W x H x 3 image (row 0 = top)
 __global__ void k_untile(const float4 *local, const int32_t *local_blocks, int n_local_px, int blocks_x, int width, int height, float *rgb)
 {

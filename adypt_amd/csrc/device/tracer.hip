@@ -80,6 +80,7 @@ struct adypt_ctx {
 	uint32_t shift_seed_loaded = 0;
 	bool shift_loaded = false;
 	int instrumentation = 0;
+	int view_type = 0;          // uuViewer.uType of the image in d_accum: the viewer type of the last primary frame, 3 after path tracing
 
 	std::vector<EventPair> events;
 	std::vector<EventPair> free_events;
@@ -579,6 +580,7 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	HIP_TRY(c, hipSetDevice(c->device));
 	// Trace(false): leaves path-tracing mode (OglPathTracer.cpp:53-58)
 	c->pt_started = false; c->spp = 0;
+	c->view_type = viewer_type;
 	int r = apply_params(c);
 	if(r != ADYPT_OK) return r;
 	FrameArgs f; SceneArgs sc; PixelArgs px;
@@ -624,6 +626,7 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 			HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)std::max(c->n_local_px, 64) * sizeof(float4), c->stream));
 			c->spp = 0;
 			c->pt_started = true;
+			c->view_type = 3; // kPTRadiance (OglPathTracer.cpp:38)
 		}
 		const int max_bounce = c->params.max_bounce, life = c->params.tmp_lifetime;
 		// Batch = up to frames_in_flight consecutive frames traced as ONE wavefront (frames are independent samples; the
@@ -714,6 +717,30 @@ int adypt_read_radiance(adypt_ctx *c, float *rgb)
 	std::vector<float> local((size_t)c->n_local_px * 4);
 	HIP_TRY(c, hipMemcpy(local.data(), c->d_accum, local.size() * sizeof(float), hipMemcpyDeviceToHost));
 	return adypt_untile_host(c->width, c->height, c->rank, c->nranks, local.data(), rgb);
+}
+
+int adypt_read_display(adypt_ctx *c, uint8_t *rgba8)
+{
+	if(!c || !rgba8) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	uint32_t *d_out = nullptr;
+	HIP_TRY(c, hipMalloc((void **)&d_out, (size_t)std::max(c->n_local_px, 64) * sizeof(uint32_t)));
+	hipLaunchKernelGGL(k_display, dim3((c->n_local_px + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_accum, c->n_local_px, c->view_type, d_out);
+	std::vector<uint32_t> local((size_t)c->n_local_px);
+	hipError_t e = hipGetLastError();
+	if(e == hipSuccess) e = hipMemcpyAsync(local.data(), d_out, local.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+	if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	(void)hipFree(d_out);
+	HIP_TRY(c, e);
+	for(int L = 0; L < c->n_local_px; ++L)
+	{
+		const int blk = c->local_blocks[(size_t)(L >> 10)];
+		const int in = L & 1023, wt = in >> 6, ln = in & 63;
+		const int x = (blk % c->blocks_x) * kBlockDim + (wt & 3) * 8 + (ln & 7), y = (blk / c->blocks_x) * kBlockDim + (wt >> 2) * 8 + (ln >> 3);
+		if(x >= c->width || y >= c->height) continue;
+		memcpy(rgba8 + ((size_t)y * c->width + x) * 4, &local[(size_t)L], 4);
+	}
+	return ADYPT_OK;
 }
 
 int adypt_read_hits(adypt_ctx *c, int32_t *tri, float *uv)

@@ -356,6 +356,44 @@ void adypt_camera_matrices(float fov, float yaw, float pitch, int width, int hei
 	inverse4(view, inv_view);
 }
 
+// 8-bit RGBA -> PNG (colour type 6, one zlib stream, filter 0 on every row): the headless stand-in for the window
+int adypt_save_png(const char *path, const uint8_t *rgba8, int width, int height)
+{
+	if(!path || !rgba8 || width <= 0 || height <= 0) { set_host_error("adypt_save_png: bad argument"); return ADYPT_E_INVALID; }
+	std::vector<uint8_t> raw((size_t)height * ((size_t)width * 4 + 1));
+	for(int y = 0; y < height; ++y)
+	{
+		uint8_t *row = raw.data() + (size_t)y * ((size_t)width * 4 + 1);
+		row[0] = 0;
+		memcpy(row + 1, rgba8 + (size_t)y * width * 4, (size_t)width * 4);
+	}
+	uLongf zlen = compressBound((uLong)raw.size());
+	std::vector<uint8_t> z(zlen);
+	if(compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { set_host_error("adypt_save_png: zlib failed"); return ADYPT_E_IO; }
+	std::ofstream os(path, std::ios::binary);
+	if(!os.is_open()) { set_host_error(std::string("cannot write ") + path); return ADYPT_E_IO; }
+	auto be32 = [](uint8_t *o, uint32_t v) { o[0] = (uint8_t)(v >> 24); o[1] = (uint8_t)(v >> 16); o[2] = (uint8_t)(v >> 8); o[3] = (uint8_t)v; };
+	auto chunk = [&](const char *type, const uint8_t *data, size_t n) {
+		uint8_t hdr[8];
+		be32(hdr, (uint32_t)n); memcpy(hdr + 4, type, 4);
+		os.write((const char *)hdr, 8);
+		if(n) os.write((const char *)data, (std::streamsize)n);
+		uLong crc = crc32(0L, (const Bytef *)type, 4);
+		if(n) crc = crc32(crc, data, (uInt)n);
+		uint8_t tail[4]; be32(tail, (uint32_t)crc);
+		os.write((const char *)tail, 4);
+	};
+	static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+	os.write((const char *)sig, 8);
+	uint8_t ihdr[13];
+	be32(ihdr, (uint32_t)width); be32(ihdr + 4, (uint32_t)height);
+	ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+	chunk("IHDR", ihdr, 13);
+	chunk("IDAT", z.data(), (size_t)zlen);
+	chunk("IEND", nullptr, 0);
+	return os.good() ? ADYPT_OK : ADYPT_E_IO;
+}
+
 int adypt_sobol_points(int dim, int first, int n, float *out)
 {
 	if(dim < 0 || dim > 64 || first < 0 || n < 0 || !out) { set_host_error("adypt_sobol_points: dim must be <= 64"); return ADYPT_E_INVALID; }

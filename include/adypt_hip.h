@@ -129,6 +129,12 @@ int adypt_get_frames_in_flight(const adypt_ctx *ctx);
 /* glGetTextureImage(m_result_tex, GL_RGB, GL_FLOAT) of OglPathTracer::SaveResult (OglPathTracer.cpp:203-205):
  * W*H*3 floats, row 0 = top of the image.  Pixels of blocks this context does not own are left untouched. */
 int adypt_read_radiance(adypt_ctx *ctx, float *rgb);
+/* What OglPathTracer::DrawScreen shows (shaders/screen.glsl:15-21 over the result image, src/Tracer/OglPathTracer.cpp
+ * DrawScreen): gamma 1/2.2 for viewer types <= 3 (diffuse, specular, emissive, path-traced radiance), normalize * 0.5 +
+ * 0.5 for the normal / position viewers, as 8-bit RGBA (W*H*4 bytes, row 0 = top, alpha 255).  The viewer type is the
+ * one of the frame in the result image (the last adypt_trace_primary's, 3 after adypt_trace_spp).  Pixels of blocks
+ * this context does not own are left untouched. */
+int adypt_read_display(adypt_ctx *ctx, uint8_t *rgba8);
 /* content of image 1 (uPrimaryTmpImg, pathtracer.glsl:114-127): scene triangle id and uv of the cached primary hit */
 int adypt_read_hits(adypt_ctx *ctx, int32_t *tri, float *uv);
 

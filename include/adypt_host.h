@@ -86,6 +86,8 @@ void adypt_shift_bytes(uint32_t seed, int width, int height, uint8_t *out);
 /* SaveEXR(rgb, W, H, 3, fp16, path) as OglPathTracer::SaveResult calls it (OglPathTracer.cpp:207): scanline,
  * ZIP, channels B,G,R, HALF or FLOAT */
 int adypt_save_exr(const char *path, const float *rgb, int width, int height, int save_as_fp16);
+/* 8-bit RGBA (adypt_read_display) -> PNG: the headless stand-in for the reference's window */
+int adypt_save_png(const char *path, const uint8_t *rgba8, int width, int height);
 /* minimal reader of the files adypt_save_exr writes (round-trip tests / tools) */
 int adypt_load_exr(const char *path, float **rgb, int *width, int *height);
 void adypt_free(void *p);

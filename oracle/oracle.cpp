@@ -758,6 +758,34 @@ ORC_API void orc_trace_any(const OrcScene *sc, int stack_size, const float *rays
 	trace_batch(sc, stack_size, rays, n, hits, n_threads, true);
 }
 
+// screen.glsl main (:15-21) + the RGBA8 UNORM colour buffer it is drawn into: rgba W*H*4 floats -> out W*H*4 bytes.
+// uType <= 3: pow(v.xyz, 1/2.2) (exponent = the binary32 quotient 1.0f / 2.2f); else normalize(v.xyz) * 0.5 + 0.5.
+static uint8_t unorm8(float c)
+{
+	if(!(c > 0.0f)) return 0; // also NaN
+	if(c >= 1.0f) return 255;
+	return (uint8_t)floorf(fmaf(c, 255.0f, 0.5f));
+}
+ORC_API void orc_display(const float *rgba, int64_t n_px, int viewer_type, uint8_t *out)
+{
+	for(int64_t i = 0; i < n_px; ++i)
+	{
+		const float *v = rgba + i * 4;
+		float c[3];
+		if(viewer_type <= 3)
+		{
+			const float g = 1.0f / 2.2f;
+			for(int k = 0; k < 3; ++k) c[k] = canon_pow(v[k], g);
+		}
+		else
+		{
+			V3 nn = normalize3(v3(v[0], v[1], v[2]));
+			c[0] = nn.x * 0.5f + 0.5f; c[1] = nn.y * 0.5f + 0.5f; c[2] = nn.z * 0.5f + 0.5f;
+		}
+		out[i * 4 + 0] = unorm8(c[0]); out[i * 4 + 1] = unorm8(c[1]); out[i * 4 + 2] = unorm8(c[2]); out[i * 4 + 3] = 255;
+	}
+}
+
 // primaryray.glsl main (:46-94).  rgba: W*H*4.  hits (optional): W*H OrcHit records.
 ORC_API void orc_primary_frame(const OrcScene *sc, const OrcParams *p, int viewer_type, float *rgba, OrcHit *hits,
 							   OrcStats *stats, int n_threads)

@@ -205,6 +205,15 @@ def trace(scene: Scene, rays: np.ndarray, stack_size: int = 24, n_threads: Optio
     return hits
 
 
+def display(rgba: np.ndarray, viewer_type: int) -> np.ndarray:
+    """shaders/screen.glsl:15-21 into an RGBA8 colour buffer: H x W x 4 float32 -> H x W x 4 uint8."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    assert rgba.shape[-1] == 4
+    out = np.empty(rgba.shape, dtype=np.uint8)
+    lib().orc_display(_p(rgba), C.c_int64(rgba.size // 4), C.c_int(viewer_type), _p(out))
+    return out
+
+
 def primary_frame(scene: Scene, params: _Params, viewer_type: int = 0, n_threads: Optional[int] = None):
     w, h = params.width, params.height
     rgba = np.empty((h, w, 4), dtype=np.float32)

@@ -235,3 +235,25 @@ def test_cli_headless_instance(scene_cache, tmp_path):
     assert inst.InitializeFromFile(spec.config_path, shift_seed=77)
     inst.m_path_tracer.Trace(True, 3)
     assert np.array_equal(bits(api.load_exr(out)), bits(inst.m_path_tracer.ReadResult()))
+
+
+@pytest.mark.parametrize("viewer", [0, 1, 2, 4, 5])
+def test_display_transform_matches_oracle(viewer, scene_cache, sobol_matrices):
+    """adypt_read_display = shaders/screen.glsl over the result image (f4): every byte equals the oracle's."""
+    inst = make_instance(scene_cache, "tiny0", 100, 75, pt={"maxBounce": 4})
+    pt = inst.m_path_tracer
+    c = inst.m_config.c
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    pt.m_viewer_type = viewer
+    pt.Trace(False)
+    rgba, _, _ = O.primary_frame(osc, P, viewer)
+    assert np.array_equal(pt.ReadDisplay(), O.display(rgba, viewer))
+    if viewer == 0:
+        pt.Trace(True, 3)  # path-traced radiance is shown with uType = 3 (gamma)
+        st = O.PathTracerState(c.width, c.height)
+        O.pt_frames(osc, P, O.shift_bytes(99, c.width, c.height), sobol_matrices, st, 3)
+        acc = st.accum.copy()
+        acc[..., 3] = 1.0
+        shown = pt.ReadDisplay()
+        assert np.array_equal(shown, O.display(acc, 3))
+        assert shown[..., :3].max() > 100  # not a black frame

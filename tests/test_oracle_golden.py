@@ -114,3 +114,43 @@ def test_canonical_sincos_pow_close_to_libm():
     assert np.array_equal(bits(O.pow_(base, np.ones_like(base))), bits(base))
     assert np.isnan(O.pow_(np.array([-0.5], np.float32), np.array([0.3], np.float32))[0])
     assert O.pow_(np.array([0.0], np.float32), np.array([0.3], np.float32))[0] == 0.0
+
+
+def test_display_transform_and_png_writer(tmp_path):
+    """shaders/screen.glsl:15-21 restated (gamma 1/2.2 for viewer types <= 3, normalize*0.5+0.5 for 4/5) into RGBA8, and
+    the PNG writer of the headless preview: decoded with zlib, CRCs checked."""
+    import struct
+    import zlib
+    from adypt_amd import api
+    rs = np.random.RandomState(1)
+    img = np.concatenate([rs.uniform(-0.2, 3, (20, 30, 3)).astype(np.float32), np.ones((20, 30, 1), np.float32)], -1)
+    img[0, 0, :3] = [0, 1, np.nan]
+    img[0, 1, :3] = [np.inf, -np.inf, 0.5]
+    d = O.display(img, 3)
+    assert d.dtype == np.uint8 and d.shape == (20, 30, 4) and (d[..., 3] == 255).all()
+    assert d[0, 0].tolist() == [0, 255, 0, 255] and d[0, 1].tolist() == [255, 0, 186, 255]      # NaN -> 0, +-inf clamp
+    ref = np.clip(np.nan_to_num(np.power(np.maximum(img[..., :3].astype(np.float64), 0), 1 / 2.2), nan=0, posinf=1), 0, 1)
+    assert np.abs(d[..., :3].astype(int) - np.floor(ref * 255 + 0.5).astype(int)).max() <= 1
+    for t in (0, 1, 2):
+        assert np.array_equal(O.display(img, t), d)
+    n4 = O.display(img[1:], 4)
+    nrm = img[1:, :, :3] / np.linalg.norm(img[1:, :, :3], axis=-1, keepdims=True)
+    assert np.abs(n4[..., :3].astype(int) - np.floor((nrm * 0.5 + 0.5) * 255 + 0.5).astype(int)).max() <= 1
+    assert np.array_equal(O.display(img[1:], 5), n4)
+    p = str(tmp_path / "o.png")
+    api.save_png(p, d)
+    raw = open(p, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, = struct.unpack(">I", raw[pos:pos + 4])
+        t, data = raw[pos + 4:pos + 8], raw[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(t + data) & 0xFFFFFFFF == crc
+        chunks.append((t, data))
+        pos += 12 + n
+    assert [t for t, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[0][1][:10])
+    assert (w, h, depth, ctype) == (30, 20, 8, 6)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, w * 4 + 1)
+    assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(h, w, 4), d)
