@@ -100,6 +100,7 @@ _SIGS = {
     "adypt_read_display": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adypt_local_radiance_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "adypt_copy_local_radiance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "adypt_assemble_radiance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "adypt_shard_block_count": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "adypt_untile_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     # adypt_host.h

@@ -401,6 +401,9 @@ class HipPathTracer:
     def copy_local_radiance(self, dst_device_ptr: int, capacity_float4: int) -> None:
         N.check(N.lib.adypt_copy_local_radiance(self._ctx, dst_device_ptr, capacity_float4), self._ctx)
 
+    def assemble_radiance(self, gathered_device_ptr: int, stride_float4: int, rgb_device_ptr: int) -> None:
+        N.check(N.lib.adypt_assemble_radiance(self._ctx, gathered_device_ptr, stride_float4, rgb_device_ptr), self._ctx)
+
     def destroy(self) -> None:
         if self._ctx:
             N.lib.adypt_destroy(self._ctx)

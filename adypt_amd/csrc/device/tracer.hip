@@ -42,6 +42,8 @@ struct adypt_ctx {
 	// scene (immutable after create)
 	void *d_nodes = nullptr, *d_woop = nullptr, *d_tri_indices = nullptr, *d_triangles = nullptr, *d_materials = nullptr;
 	void *d_texels = nullptr, *d_tex_desc = nullptr, *d_local_blocks = nullptr;
+	void *d_all_blocks = nullptr;             // adypt_assemble_radiance: block lists of all ranks
+	std::vector<int64_t> all_blocks_offset;
 	int64_t n_nodes = 0, n_refs = 0, n_tris = 0, n_mats = 0;
 	int n_tex = 0;
 	int width = 0, height = 0, blocks_x = 0, blocks_y = 0, rank = 0, nranks = 1;
@@ -513,7 +515,7 @@ void adypt_destroy(adypt_ctx *c)
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	for(EventPair &p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-	void *bufs[] = {c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
+	void *bufs[] = {c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
 					c->d_accum, c->d_cache, c->d_cache_next, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
 					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol};
 	for(void *b : bufs) if(b) (void)hipFree(b);
@@ -881,6 +883,38 @@ int adypt_copy_local_radiance(adypt_ctx *c, void *dst, int64_t capacity_float4)
 	HIP_TRY(c, hipMemcpyAsync(dst, c->d_accum, (size_t)c->n_local_px * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
 	if(capacity_float4 > c->n_local_px)
 		HIP_TRY(c, hipMemsetAsync((char *)dst + (size_t)c->n_local_px * sizeof(float4), 0, (size_t)(capacity_float4 - c->n_local_px) * sizeof(float4), c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return ADYPT_OK;
+}
+
+int adypt_assemble_radiance(adypt_ctx *c, const void *gathered, int64_t stride_float4, void *rgb_device)
+{
+	if(!c || !gathered || !rgb_device || stride_float4 < 0) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	if(!c->d_all_blocks)
+	{
+		// block lists of every rank of the shard, back to back (uploaded once)
+		std::vector<int32_t> all;
+		c->all_blocks_offset.assign(1, 0);
+		for(int r = 0; r < c->nranks; ++r)
+		{
+			const std::vector<int32_t> b = owned_blocks(c->width, c->height, r, c->nranks);
+			all.insert(all.end(), b.begin(), b.end());
+			c->all_blocks_offset.push_back((int64_t)all.size());
+		}
+		int rr = upload(c, &c->d_all_blocks, all.data(), all.size());
+		if(rr != ADYPT_OK) return rr;
+	}
+	for(int r = 0; r < c->nranks; ++r)
+	{
+		const int64_t n_blocks = c->all_blocks_offset[(size_t)r + 1] - c->all_blocks_offset[(size_t)r];
+		const int n_px = (int)(n_blocks * kBlockPixels);
+		if(n_px == 0) continue;
+		if(stride_float4 < n_px) return fail(c, ADYPT_E_INVALID, "adypt_assemble_radiance: stride smaller than a rank's buffer");
+		hipLaunchKernelGGL(k_untile, dim3((n_px + 255) / 256), dim3(256), 0, c->stream, (const float4 *)gathered + (size_t)r * (size_t)stride_float4,
+						   (const int32_t *)c->d_all_blocks + c->all_blocks_offset[(size_t)r], n_px, c->blocks_x, c->width, c->height, (float *)rgb_device);
+	}
+	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return ADYPT_OK;
 }

@@ -82,3 +82,25 @@ def gather_radiance(local, width: int, height: int, rank: int, world: int, group
     for r in range(world):
         untile(width, height, r, world, parts[r].detach().cpu().numpy(), rgb)
     return rgb
+
+
+def gather_radiance_device(local, tracer, width: int, height: int, rank: int, world: int, group=None):
+    """GPU-resident variant of `gather_radiance` (backend "nccl" = RCCL, or world == 1): the one gather lands in a
+    contiguous device buffer on rank 0, which un-tiles all ranks' blocks on the device (`adypt_assemble_radiance`).
+    Returns the assembled H x W x 3 float32 *device* tensor on rank 0, None elsewhere — nothing crosses PCIe."""
+    import torch
+    import torch.distributed as dist
+    n = max_block_count(width, height, world) * BLOCK_PIXELS * 4
+    assert local.is_cuda and local.numel() == n and local.dtype == torch.float32
+    if world == 1:
+        gathered = local
+    else:
+        gathered = torch.empty(world * n, dtype=torch.float32, device=local.device) if rank == 0 else None
+        parts = list(gathered.view(world, n).unbind(0)) if rank == 0 else None
+        dist.gather(local, gather_list=parts, dst=0, group=group)  # the single collective of the data path
+    if rank != 0:
+        return None
+    rgb = torch.empty((height, width, 3), dtype=torch.float32, device=local.device)
+    torch.cuda.current_stream(local.device).synchronize()  # the gather ran on torch's stream, the un-tiling runs on the tracer's
+    tracer.assemble_radiance(gathered.data_ptr(), n // 4, rgb.data_ptr())
+    return rgb

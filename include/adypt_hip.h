@@ -164,6 +164,10 @@ int adypt_local_radiance_device(adypt_ctx *ctx, void **dptr);
 /* device-to-device copy of the compact local radiance into caller-owned device memory (e.g. a torch tensor that
  * a torch.distributed / RCCL gather then sends): copies local_pixel_count float4, zero-fills up to capacity_float4 */
 int adypt_copy_local_radiance(adypt_ctx *ctx, void *dst_device, int64_t capacity_float4);
+/* On the rank that received the gather: un-tile the compact buffers of all `tile_nranks` ranks (device memory, rank r at
+ * gathered + r * stride_float4 float4) into one W*H*3 fp32 image in device memory (row 0 = top) — the assembled
+ * equivalent of the reference's result texture (OglPathTracer.cpp:203-205 reads it back with glGetTextureImage). */
+int adypt_assemble_radiance(adypt_ctx *ctx, const void *gathered_device, int64_t stride_float4, void *rgb_device);
 /* blocks owned by `rank` out of `nranks` for a width x height image (same function the contexts use) */
 int64_t adypt_shard_block_count(int width, int height, int rank, int nranks);
 /* scatter one rank's compact buffer (host memory, block-major float4) into a W*H*3 host image */

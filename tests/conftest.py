@@ -15,6 +15,18 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session", autouse=True)
+def _torch_runtime_first():
+    """On a GPU box, let torch bring up its HIP runtime before libadypt_hip.so touches the device (the order bench.py
+    uses): torch ships its own copy of the runtime and reports "No HIP GPUs are available" when it initialises second."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+
+
+@pytest.fixture(scope="session", autouse=True)
 def _built():
     """The HIP library and the oracle are built in-tree before any test imports them."""
     import __graft_entry__ as g

@@ -187,6 +187,30 @@ def test_tile_shards_reassemble_bit_exact(scene_cache):
     assert rays == full.m_path_tracer.GetStats()["rays"]
 
 
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_device_side_assembly_of_gathered_shards(world, scene_cache):
+    """What rank 0 does after the one gather (adypt_assemble_radiance): the compact buffers of all ranks, laid out as the
+    gather delivers them, are un-tiled on the device into the W x H x 3 image == the 1-context frame."""
+    import torch
+    w, h, spp = 200, 120, 2
+    full = make_instance(scene_cache, "tiny0", w, h, seed=5)
+    full.m_path_tracer.Trace(True, spp)
+    ref = full.m_path_tracer.ReadResult()
+    n = D.max_block_count(w, h, world) * D.BLOCK_PIXELS * 4
+    gathered = torch.full((world * n,), float("nan"), dtype=torch.float32, device="cuda")
+    parts = [make_instance(scene_cache, "tiny0", w, h, seed=5, rank=r, world=world) for r in range(world)]
+    for r, part in enumerate(parts):
+        part.m_path_tracer.Trace(True, spp)
+        part.m_path_tracer.copy_local_radiance(gathered[r * n:(r + 1) * n].data_ptr(), n // 4)
+    rgb = torch.full((h, w, 3), float("nan"), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    parts[0].m_path_tracer.assemble_radiance(gathered.data_ptr(), n // 4, rgb.data_ptr())
+    assert np.array_equal(bits(rgb.cpu().numpy()), bits(ref))
+    if world == 1:  # the single-process path of bench.py
+        img = D.gather_radiance_device(gathered, parts[0].m_path_tracer, w, h, 0, 1)
+        assert np.array_equal(bits(img.cpu().numpy()), bits(ref))
+
+
 def test_full_size_frame_bit_exact_and_deterministic(scene_cache, sobol_matrices):
     """BASELINE config 2/3 size (1920x1080, sponza stand-in, 8 bounces): primary hits and one path-traced frame equal
     the oracle pixel for pixel; re-running gives identical bits; rays are counted exactly."""
