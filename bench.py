@@ -178,9 +178,18 @@ def main() -> None:
             cpu_t += time.perf_counter() - t1
             cpu_rays += s.rays
             frames += 1
+        # one thread (SURVEY.md §8d asks for both): a quarter-height frame keeps it to a few seconds
+        P1 = O.make_params(c.width, c.height // 4, list(c.position), *O.camera(c.fov, c.yaw, c.pitch, c.width, c.height // 4), stack_size=c.stack_size,
+                           max_bounce=c.max_bounce, subpixel=c.subpixel, tmp_life=1, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))
+        st1 = O.PathTracerState(c.width, c.height // 4)
+        t1 = time.perf_counter()
+        s1 = O.pt_frames(osc, P1, O.shift_bytes(12345, c.width, c.height // 4), sm, st1, 1, n_threads=1)
+        t1 = time.perf_counter() - t1
         cpu = {"value": round(cpu_rays / cpu_t / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
                "sample": "%d full %dx%d frames (every frame traces its primaries), %d rays, %.1f s, oracle/liboracle.so on %d threads"
-                         % (frames, c.width, c.height, cpu_rays, cpu_t, cores)}
+                         % (frames, c.width, c.height, cpu_rays, cpu_t, cores),
+               "value_1_thread": round(s1.rays / t1 / 1e6, 3),
+               "sample_1_thread": "one %dx%d frame, %d rays, %.1f s" % (c.width, c.height // 4, s1.rays, t1)}
 
     if rank == 0:
         value = total_rays / elapsed / 1e6
