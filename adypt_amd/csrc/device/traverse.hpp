@@ -174,11 +174,22 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			if(can_pop)
 			{
 				--sp;
-				const uint2 g = sp < a.lds_depth ? my_stack[sp * 64] : my_spill[(size_t)(sp - a.lds_depth) * total_lanes];
-				ng_x = g.x; ng_y = g.y;
-				// complete the pop here (LDS read, or the rare spill read from global memory) so that no older
-				// memory operation is pending when the triangle / node loads below are issued
-				asm volatile("" : "+v"(ng_x), "+v"(ng_y));
+				// two separate loads, each completed inside its branch: written as one select the compiler emits a single
+				// flat_load (LDS or global decided by address) that waits on both memory counters; the LDS pop is the hot one.
+				// Completing the pop here also means no older memory operation is pending when the triangle / node loads
+				// below are issued.
+				if(sp < a.lds_depth)
+				{
+					const uint2 g = my_stack[sp * 64];
+					ng_x = g.x; ng_y = g.y;
+					asm volatile("" : "+v"(ng_x), "+v"(ng_y));
+				}
+				else
+				{
+					const uint2 g = my_spill[(size_t)(sp - a.lds_depth) * total_lanes];
+					ng_x = g.x; ng_y = g.y;
+					asm volatile("" : "+v"(ng_x), "+v"(ng_y));
+				}
 			}
 			const bool choose = !pending && ng_y > 0x00ffffffu;
 			if(choose)
