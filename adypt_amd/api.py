@@ -330,6 +330,14 @@ class HipPathTracer:
                 self.m_viewer_type = ViewerTypes.kDiffuse
             N.check(N.lib.adypt_trace_primary(self._ctx, self.m_viewer_type), self._ctx)
 
+    def TraceAsync(self, n_spp: int = 1) -> None:
+        """Trace(true) n_spp times without waiting for the GPU (adypt_trace_spp_async); pair with Wait()."""
+        self.m_viewer_type = ViewerTypes.kPTRadiance
+        N.check(N.lib.adypt_trace_spp_async(self._ctx, n_spp), self._ctx)
+
+    def Wait(self) -> None:
+        N.check(N.lib.adypt_wait(self._ctx), self._ctx)
+
     def Reset(self) -> None:
         N.check(N.lib.adypt_reset(self._ctx), self._ctx)
 

@@ -63,6 +63,12 @@ struct adypt_ctx {
 	float4 *d_hit = nullptr;
 	float4 *d_done = nullptr;  // [frames_in_flight][local pixels] finished samples of a multi-frame batch
 	float *d_sobol = nullptr;  // [kMaxFramesInFlight][64] Sobol points of the frames of the current batch
+	// pinned staging of the Sobol points, one slot per batch in flight on the stream: the upload is then a true
+	// asynchronous copy and enqueueing a batch never waits for the GPU (adypt_trace_spp_async)
+	static constexpr int kSobolSlots = 4;
+	float *h_sobol[kSobolSlots] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t sobol_done[kSobolSlots] = {nullptr, nullptr, nullptr, nullptr};
+	int sobol_next = 0;
 	int frames_in_flight = 1;
 	RayStats *d_ray_stats = nullptr;
 	FrameCounters *d_counters = nullptr;
@@ -519,6 +525,11 @@ void adypt_destroy(adypt_ctx *c)
 					c->d_accum, c->d_cache, c->d_cache_next, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
 					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol};
 	for(void *b : bufs) if(b) (void)hipFree(b);
+	for(int i = 0; i < adypt_ctx::kSobolSlots; ++i)
+	{
+		if(c->h_sobol[i]) (void)hipHostFree(c->h_sobol[i]);
+		if(c->sobol_done[i]) (void)hipEventDestroy(c->sobol_done[i]);
+	}
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -609,7 +620,22 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	return check_async_errors(c);
 }
 
+int adypt_wait(adypt_ctx *c)
+{
+	if(!c) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	harvest_events(c);
+	return check_async_errors(c);
+}
+
 int adypt_trace_spp(adypt_ctx *c, int n_spp)
+{
+	int r = adypt_trace_spp_async(c, n_spp);
+	return r != ADYPT_OK ? r : adypt_wait(c);
+}
+
+int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 {
 	if(!c || n_spp < 0) return ADYPT_E_INVALID;
 	if(!c->have_camera) return fail(c, ADYPT_E_STATE, "adypt_trace_spp: call adypt_set_camera first");
@@ -649,11 +675,22 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 		fill_frame(c, &f);
 		{
 			// Sobol::Next (src/Util/Sobol.cpp:16-21) for the m frames of the batch
-			std::vector<float> pts((size_t)m * 2 * max_bounce), padded((size_t)m * 64, 0.0f);
+			const int slot = c->sobol_next;
+			c->sobol_next = (slot + 1) % adypt_ctx::kSobolSlots;
+			if(!c->h_sobol[slot])
+			{
+				HIP_TRY(c, hipHostMalloc((void **)&c->h_sobol[slot], (size_t)kMaxFramesInFlight * 64 * sizeof(float), hipHostMallocDefault));
+				HIP_TRY(c, hipEventCreateWithFlags(&c->sobol_done[slot], hipEventDisableTiming));
+			}
+			else HIP_TRY(c, hipEventSynchronize(c->sobol_done[slot])); // the copy that last used this slot has left it
+			std::vector<float> pts((size_t)m * 2 * max_bounce);
 			int r = adypt_sobol_points(2 * max_bounce, c->spp, m, pts.data());
 			if(r != ADYPT_OK) return fail(c, r, adypt_host_last_error());
+			float *padded = c->h_sobol[slot];
+			memset(padded, 0, (size_t)m * 64 * sizeof(float));
 			for(int k = 0; k < m; ++k) memcpy(&padded[(size_t)k * 64], &pts[(size_t)k * 2 * max_bounce], sizeof(float) * 2 * (size_t)max_bounce);
-			HIP_TRY(c, hipMemcpyAsync(c->d_sobol, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+			HIP_TRY(c, hipMemcpyAsync(c->d_sobol, padded, (size_t)m * 64 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+			HIP_TRY(c, hipEventRecord(c->sobol_done[slot], c->stream));
 		}
 		HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
 		int use_cache = (m == 1 && n_retrace) ? 0 : 1;
@@ -707,9 +744,7 @@ int adypt_trace_spp(adypt_ctx *c, int n_spp)
 		c->spp += m;
 		remaining -= m;
 	}
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	harvest_events(c);
-	return check_async_errors(c);
+	return ADYPT_OK; // everything is enqueued on the context's stream; adypt_wait collects errors and kernel timings
 }
 
 int adypt_read_radiance(adypt_ctx *c, float *rgb)

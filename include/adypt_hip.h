@@ -117,9 +117,14 @@ int adypt_trace_primary(adypt_ctx *ctx, int viewer_type);
 /* OglPathTracer::Trace(true), n_spp times: per frame Sobol::Next, spp++, wavefront passes.  The first call after
  * adypt_reset()/adypt_trace_primary() clears the result image and restarts the Sobol sequence (OglPathTracer.cpp:39-46). */
 int adypt_trace_spp(adypt_ctx *ctx, int n_spp);
+/* The same, returning as soon as the frames are enqueued on the context's stream (one host thread can then keep several
+ * contexts = GPUs busy); adypt_wait blocks until the context is idle and reports what adypt_trace_spp would have
+ * (stack overflow, HIP errors).  Every other entry point that reads results synchronises by itself. */
+int adypt_trace_spp_async(adypt_ctx *ctx, int n_spp);
+int adypt_wait(adypt_ctx *ctx);
 int adypt_reset(adypt_ctx *ctx);
 int adypt_get_spp(const adypt_ctx *ctx); /* OglPathTracer::GetSPP */
-/* How many consecutive frames adypt_trace_spp traces as one wavefront pass (1..16).  Frames are independent
+/* How many consecutive frames adypt_trace_spp traces as one wavefront pass (1..128).  Frames are independent
  * samples and the running mean is applied afterwards in frame order, so results are bit-identical for every value;
  * more frames in flight keep small images / tile shards saturated.  Default: chosen from the local pixel count
  * (about 4 M paths per pass, at most 8).  Reallocates the ray queues. */

@@ -211,6 +211,34 @@ def test_device_side_assembly_of_gathered_shards(world, scene_cache):
         assert np.array_equal(bits(img.cpu().numpy()), bits(ref))
 
 
+def test_async_enqueue_of_several_contexts_from_one_thread(scene_cache):
+    """adypt_trace_spp_async / adypt_wait: one host thread keeps several contexts (here the two tile shards of one image,
+    on the same GPU) busy at once; results equal the synchronous calls, errors surface at adypt_wait."""
+    w, h, spp = 256, 144, 9
+    full = make_instance(scene_cache, "tiny0", w, h, seed=5, pt={"tmpLifetime": 4})
+    full.m_path_tracer.Trace(True, spp)
+    ref = full.m_path_tracer.ReadResult()
+    parts = [make_instance(scene_cache, "tiny0", w, h, seed=5, rank=r, world=2, pt={"tmpLifetime": 4}) for r in range(2)]
+    for p in parts:
+        p.m_path_tracer.SetFramesInFlight(2)  # several batches per call: enqueueing must not wait for the previous batch
+        p.m_path_tracer.TraceAsync(spp - 4)
+    for p in parts:
+        p.m_path_tracer.TraceAsync(4)
+    out = np.zeros_like(ref)
+    for r, p in enumerate(parts):
+        p.m_path_tracer.Wait()
+        assert p.m_path_tracer.GetSPP() == spp
+        mask = D.owner_mask(w, h, r, 2).astype(bool)
+        out[mask] = p.m_path_tracer.ReadResult()[mask]
+    assert np.array_equal(bits(out), bits(ref))
+    # a stack overflow raised by asynchronous work is reported by Wait()
+    bad = make_instance(scene_cache, "sibenik", 64, 36, pt={"stackSize": 1})
+    bad.m_path_tracer.TraceAsync(1)
+    with pytest.raises(N.AdyptError) as e:
+        bad.m_path_tracer.Wait()
+    assert e.value.code == N.E_STACK_OVERFLOW
+
+
 def test_full_size_frame_bit_exact_and_deterministic(scene_cache, sobol_matrices):
     """BASELINE config 2/3 size (1920x1080, sponza stand-in, 8 bounces): primary hits and one path-traced frame equal
     the oracle pixel for pixel; re-running gives identical bits; rays are counted exactly."""
