@@ -154,6 +154,8 @@ def main() -> None:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
         if world == 1 and (args.scene, args.width, args.height) == ("sponza", 1920, 1080):
             roofline["traffic"] = round(pmc["traffic_bytes_per_ray"] * st["rays"] / max(1, trace_launches))
+            # the same traffic as a rate: what the fabric (Infinity Cache + HBM) actually delivered while the kernel ran
+            roofline["traffic_GBs"] = round(pmc["traffic_bytes_per_ray"] * st["rays"] / (trace_ms * 1e-3) / 1e9, 1) if trace_ms > 0 else None
             roofline["traffic_source"] = ("profiles/r1_pmc_traffic.json: %.1f fabric bytes per ray (separate rocprofv3 --pmc passes of bench.py --steps 64 --warmup 0) "
                                           "x the rays per launch of this run; L2 hit rate %.2f" % (pmc["traffic_bytes_per_ray"], pmc["TCC_hit_rate"]))
     except (OSError, KeyError, ValueError):
