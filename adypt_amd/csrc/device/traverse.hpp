@@ -338,9 +338,11 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				ng_y = (hitmask & 0xff000000u) | (head_w >> 24);
 				tg_y = hitmask & 0x00ffffffu;
 			}
-			else
+			// ---------------- E. ray finished (traversal.glsl:245-254)? ----------------
+			// Nothing left to test, to visit or to pop — checked in the SAME trip as the slab test that found no child
+			// (or the triangle pair that was the last work): a separate trip just to notice it cost one of ~13 trips per ray.
+			if(tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))
 			{
-				// ---------------- ray finished (traversal.glsl:247-254) ----------------
 				const int32_t tri_id = hit_idx != -1 ? a.tri_indices[hit_idx] : -1;
 				a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
 				any_overflow |= overflow;
