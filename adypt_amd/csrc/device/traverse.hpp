@@ -85,6 +85,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 	uint32_t ng_x = 0, ng_y = 0, tg_x = 0, tg_y = 0;
 	uint32_t n_nodes = 0, n_tris = 0, hash = 0, max_depth = 0;
 	bool overflow = false;
+	bool flush = false;                          // the lane's ray is finished but its result is not written yet (see E / refill)
 	bool pending = false;                        // a next node is chosen (and pushed for) but not yet slab-tested
 	uint32_t node = 0, depth_after_push = 0;     // push bookkeeping is committed when the node is actually visited (D)
 	bool push_overflow = false;
@@ -123,12 +124,24 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			loc_next += got;
 			if(STATS && lane == 0) wp[6] += 1;
 			const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-			if(!active && my_rank < got)
+			// results of the rays the idle lanes finished since the last refill (traversal.glsl:253-254: remap, write):
+			// written here, >= refill_min lanes at a time and with the remap load in flight next to the loads of the new
+			// rays, instead of by the 5 lanes that finish in an average trip with a dependent load-then-store of their own
+			int32_t flush_tri = -1;
+			if(flush && hit_idx != -1) flush_tri = a.tri_indices[hit_idx];
+			const bool take = !active && my_rank < got;
+			const uint32_t new_ray = begin + my_rank;
+			float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 1, 0);
+			if(take) { ro = a.ray_o[new_ray]; rd = a.ray_d[new_ray]; }
+			if(flush)
+			{
+				a.hit[ray] = make_float4(__int_as_float(flush_tri), hit_u, hit_v, hit_t);
+				flush = false;
+			}
+			if(take)
 			{
 				// ---- ray setup (traversal.glsl:16-35) ----
-				ray = begin + my_rank;
-				const float4 ro = a.ray_o[ray];
-				const float4 rd = a.ray_d[ray];
+				ray = new_ray;
 				const float ooeps = __uint_as_float((127u - 64u) << 23);
 				F3 dir = f3(rd.x, rd.y, rd.z);
 				dir.x = fabsf(dir.x) > ooeps ? dir.x : (dir.x >= 0 ? ooeps : -ooeps);
@@ -343,8 +356,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			// (or the triangle pair that was the last work): a separate trip just to notice it cost one of ~13 trips per ray.
 			if(tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))
 			{
-				const int32_t tri_id = hit_idx != -1 ? a.tri_indices[hit_idx] : -1;
-				a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
+				flush = true; // hit_idx / u / v / t and `ray` stay in their registers until the refill (or the exit) writes them
 				any_overflow |= overflow;
 				if(STATS)
 				{
@@ -363,6 +375,11 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 		}
 	}
 
+	if(flush) // rays finished after the queue ran dry
+	{
+		const int32_t tri_id = hit_idx != -1 ? a.tri_indices[hit_idx] : -1;
+		a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
+	}
 	if(any_overflow) atomicAdd(&a.stats->overflows, 1ull);
 	if(STATS)
 	{
