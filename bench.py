@@ -144,7 +144,9 @@ def main() -> None:
                 "alg_bytes_per_launch": round(alg_bytes / max(1, trace_launches)), "alg_bytes_per_ray": round(alg_bytes / max(1, cs["rays"]), 1),
                 "nodes_per_ray": round(cs["nodes_visited"] / max(1, cs["rays"]), 2), "tris_per_ray": round(cs["tris_tested"] / max(1, cs["rays"]), 2),
                 "trace_kernel_Mrays_s": round(st["rays"] / (trace_ms * 1e3), 1) if trace_ms > 0 else None,
-                "note": "algorithmic bytes / HIP-event time of the traversal launches of rank 0; the BVH (nodes+Woop %.0f MB) is Infinity-Cache resident, so real HBM traffic is lower" %
+                "note": "algorithmic bytes / HIP-event time of the traversal launches of rank 0.  The BVH (nodes+Woop %.0f MB) is L2/Infinity-Cache "
+                        "resident, so most algorithmic bytes never reach HBM (see traffic / traffic_GBs) and frac can exceed 1; the kernel is bound "
+                        "by vector-ALU issue (profiles/: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs = its duration)" %
                         ((len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 48) / 1e6)}
 
     # `traffic`: HBM/fabric bytes per launch of the same kernel from the PMC counters (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024,
