@@ -546,6 +546,7 @@ int64_t build_sbvh(const TriRec *tris, int64_t n_tris, const Box &scene_box, con
 	{
 		if(n_threads <= 1 || n_tris <= sequential_refs()) leaves = Builder(tris, n_tris, scene_box, cfg, nodes).run();
 		else leaves = ParallelBuild(tris, n_tris, scene_box, cfg, n_threads).run(nodes);
+		std::vector<Box>().swap(sweep_scratch()); // the calling thread's scratch (the workers' died with them)
 	}
 	if(ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	return leaves;
