@@ -212,6 +212,8 @@ int ensure_spill(adypt_ctx *c, int stack_size)
 int configure_trace(adypt_ctx *c, int stack_size)
 {
 	c->lds_depth = std::max(1, std::min(stack_size, kLdsStackMax));
+	// testing / tuning hook: a smaller LDS part pushes stack entries into the global spill array (tests cover that path)
+	if(const char *ov = getenv("ADYPT_LDS_STACK_DEPTH")) c->lds_depth = std::max(1, std::min(c->lds_depth, atoi(ov)));
 	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	int per_cu = 0;
 	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));

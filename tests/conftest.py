@@ -4,6 +4,16 @@ import sys
 import numpy as np
 import pytest
 
+# torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  Loaded first, it
+# is the copy libadypt_hip.so binds to as well (same SONAME) and the process has ONE runtime; loaded second, the process
+# ends up with two runtimes and whichever touches the GPU second reports that there is no device.  conftest.py is
+# imported before any test module, so this import settles the order for the tests that use torch next to the library
+# (bench.py imports torch first for the same reason; the library itself never needs torch).
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -12,18 +22,6 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _torch_runtime_first():
-    """On a GPU box, let torch bring up its HIP runtime before libadypt_hip.so touches the device (the order bench.py
-    uses): torch ships its own copy of the runtime and reports "No HIP GPUs are available" when it initialises second."""
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except ImportError:
-        pass
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -93,3 +93,34 @@ def test_minimal_and_odd_image_sizes(w, h, tmp_path, sobol_matrices):
     img = pt.ReadResult()
     assert img.shape == (h, w, 3)
     assert np.array_equal(bits(img), bits(st.accum[..., :3]))
+
+
+@pytest.mark.parametrize("lds_depth", [1, 2, 3])
+def test_stack_spill_to_global_memory_is_bit_exact(lds_depth, scene_cache, sobol_matrices, monkeypatch):
+    """The node-group stack keeps its first entries in LDS and spills deeper ones to a global array; ordinary scenes never
+    get past the LDS part (8 entries), so the spill path is forced here by shrinking the LDS part to 1..3 entries."""
+    from adypt_amd import scenes
+    monkeypatch.setenv("ADYPT_LDS_STACK_DEPTH", str(lds_depth))
+    spec = scenes.make_scene("sibenik", scene_cache, width=160, height=90, pt={"maxBounce": 4, "stackSize": 16})
+    inst = api.Instance()
+    assert inst.InitializeFromFile(spec.config_path, shift_seed=3)
+    pt, c = inst.m_path_tracer, inst.m_config.c
+    osc = O.Scene(inst.bvh.nodes, inst.bvh.tri_indices, inst.scene.triangles, inst.scene.materials, textures=inst.scene.textures)
+    rs = np.random.RandomState(9)
+    p = np.frombuffer(inst.scene.triangles.tobytes(), dtype=O.TRI_DT)["p"].reshape(-1, 3)
+    rays = np.zeros((20000, 8), np.float32)
+    rays[:, :3] = rs.uniform(p.min(0), p.max(0), size=(20000, 3))
+    rays[:, 3] = 1e-4
+    rays[:, 4:7] = rs.normal(size=(20000, 3))
+    g, o = pt.TraceRays(rays, with_stats=True), O.trace(osc, rays, c.stack_size)
+    assert g.tobytes() == o.tobytes()
+    assert g["max_depth"].max() > lds_depth          # entries really went to the spill array
+    ga, oa = pt.TraceRays(rays, with_stats=True, any_hit=True), O.trace(osc, rays, c.stack_size, any_hit=True)
+    assert ga.tobytes() == oa.tobytes()
+    ip, iv = O.camera(c.fov, c.yaw, c.pitch, c.width, c.height)
+    P = O.make_params(c.width, c.height, list(c.position), ip, iv, stack_size=c.stack_size, max_bounce=c.max_bounce,
+                      subpixel=c.subpixel, tmp_life=c.tmp_lifetime, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))
+    pt.Trace(True, 3)
+    st = O.PathTracerState(c.width, c.height)
+    O.pt_frames(osc, P, O.shift_bytes(3, c.width, c.height), sobol_matrices, st, 3)
+    assert np.array_equal(bits(pt.ReadResult()), bits(st.accum[..., :3]))
