@@ -144,6 +144,30 @@ if not os.path.exists(LIB_PATH):
     raise ImportError("adypt_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950); there is no fallback implementation" % LIB_PATH)
 
+def _share_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and load it
+    by file name, so a process that loads libadypt_hip.so (bound to /opt/rocm's copy) *before* `import torch` ends up with
+    two runtimes, and the one that touches the GPU second finds no device.  Pre-loading torch's copy — without importing
+    torch — makes both bind to the same runtime whatever the import order.  ADYPT_NO_TORCH_RUNTIME=1 disables this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("ADYPT_NO_TORCH_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        try:
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+_share_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export what the headers declare

@@ -93,7 +93,9 @@ struct QueueArgs {
 	float4 *out_o, *out_d, *out_col;
 	const uint32_t *count_in;      // [s * kCursorStride]
 	uint32_t *count_out;           // [s * kCursorStride]
-	uint32_t seg_cap;
+	uint32_t seg_cap;              // allocated slots per segment: segment s owns [s * seg_cap, (s + 1) * seg_cap)
+	uint32_t seg_paths;            // paths per segment of THIS pass (<= seg_cap, multiple of kShadeThreads): a pass of fewer frames
+	                               //   than fit still spreads evenly over the 8 segments, and the grids cover seg_paths only
 };
 
 struct PixelArgs {
@@ -170,11 +172,11 @@ __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, Scen
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	// each segment takes a contiguous run of local pixels (= whole 32x32 blocks of the image): XCD-local coherence
 	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
-	const uint32_t pi = seg * q.seg_cap + local; // path index = frame * n_local_px + local pixel
+	const uint32_t pi = seg * q.seg_paths + local; // path index = frame ordinal * n_local_px + local pixel
 	const int ordinal = (int)(pi / (uint32_t)f.n_local_px), L = (int)(pi % (uint32_t)f.n_local_px);
 	const int frame = f.frame_first + ordinal * f.frame_stride;
 	int x = 0, y = 0;
-	const bool alive = local < q.seg_cap && ordinal < f.n_frames && local_pixel_xy(f, sc.local_blocks, L, &x, &y);
+	const bool alive = local < q.seg_paths && ordinal < f.n_frames && local_pixel_xy(f, sc.local_blocks, L, &x, &y);
 	float bx = 0.0f, by = 0.0f;
 	if(bias_mode)
 	{

@@ -279,9 +279,19 @@ void fill_pixels(const adypt_ctx *c, PixelArgs *p)
 {
 	p->accum = c->d_accum; p->cache = c->d_cache; p->cache_next = c->d_cache_next; p->shift = c->d_shift; p->stats = c->d_stats;
 }
-QueueArgs queue_args(adypt_ctx *c, int in, const uint32_t *count_in, uint32_t *count_out)
+// paths per queue segment of a pass over `frames` frames (QueueArgs::seg_paths); its kernels run 8 x seg_paths / 256 workgroups.
+// Sizing the grids for the allocated capacity instead cost ~6 ns per empty workgroup: 13 ms per 8-bounce batch at 66 M slots.
+uint32_t pass_seg_paths(const adypt_ctx *c, int frames)
+{
+	const size_t paths = (size_t)std::max(c->n_local_px, 64) * (size_t)std::max(1, frames);
+	const size_t chunks = (paths + kShadeThreads - 1) / kShadeThreads;
+	return (uint32_t)std::min<size_t>(c->seg_cap, ((chunks + kNumSegments - 1) / kNumSegments) * kShadeThreads);
+}
+
+QueueArgs queue_args(adypt_ctx *c, int in, const uint32_t *count_in, uint32_t *count_out, int frames = 0)
 {
 	QueueArgs q;
+	q.seg_paths = frames > 0 ? pass_seg_paths(c, frames) : c->seg_cap;
 	q.ray_o = c->q_o[in]; q.ray_d = c->q_d[in]; q.col = c->q_col[in];
 	q.hit = c->d_hit;
 	q.out_o = c->q_o[in ^ 1]; q.out_d = c->q_d[in ^ 1]; q.out_col = c->q_col[in ^ 1];
@@ -369,6 +379,13 @@ int apply_params(adypt_ctx *c)
 	c->params = c->pending;
 	int r = configure_trace(c, c->params.stack_size);
 	if(r != ADYPT_OK) return r;
+	// cache slices for the tmpLifetime groups a batch of frames_in_flight frames can span (none for one frame at a time)
+	const int life = std::max(1, c->params.tmp_lifetime);
+	if(c->frames_in_flight > 1)
+	{
+		r = ensure_cache_slices(c, (c->frames_in_flight - 2) / life + 1);
+		if(r != ADYPT_OK) return r;
+	}
 	return load_shift(c);
 }
 
@@ -498,6 +515,11 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		TRY_CREATE(alloc_queues(c, fif));
 	}
 	HIP_CREATE(hipMalloc((void **)&c->d_sobol, (size_t)kMaxFramesInFlight * 64 * sizeof(float)));
+	for(int i = 0; i < adypt_ctx::kSobolSlots; ++i) // allocated here, not lazily: nothing is allocated while frames are traced
+	{
+		HIP_CREATE(hipHostMalloc((void **)&c->h_sobol[i], (size_t)kMaxFramesInFlight * 64 * sizeof(float), hipHostMallocDefault));
+		HIP_CREATE(hipEventCreateWithFlags(&c->sobol_done[i], hipEventDisableTiming));
+	}
 	HIP_CREATE(hipMalloc((void **)&c->d_counters, sizeof(FrameCounters)));
 	HIP_CREATE(hipMalloc((void **)&c->d_stats, sizeof(DeviceStats)));
 	HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(FrameCounters)));
@@ -573,6 +595,19 @@ int adypt_set_instrumentation(adypt_ctx *c, int flags)
 {
 	if(!c) return ADYPT_E_INVALID;
 	c->instrumentation = flags;
+	if(flags & 1)
+	{
+		// a pool of event pairs for the kernel timing, created here rather than while frames are being traced
+		HIP_TRY(c, hipSetDevice(c->device));
+		while(c->free_events.size() + c->events.size() < 96)
+		{
+			EventPair p;
+			p.kind = 0;
+			HIP_TRY(c, hipEventCreate(&p.a));
+			HIP_TRY(c, hipEventCreate(&p.b));
+			c->free_events.push_back(p);
+		}
+	}
 	return ADYPT_OK;
 }
 
@@ -601,9 +636,9 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	FrameArgs f; SceneArgs sc; PixelArgs px;
 	fill_frame(c, &f); fill_scene(c, &sc); fill_pixels(c, &px);
 	HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
-	const int grid_c = (int)(c->capacity / kShadeThreads); // kNumSegments x chunks per segment
+	const int grid_c = (int)(kNumSegments * (pass_seg_paths(c, 1) / kShadeThreads)); // kNumSegments x chunks per segment of a one-frame pass
 	{
-		QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0]); // writes queue 0
+		QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0], 1); // writes queue 0
 		hipEvent_t *stop = begin_timing(c, 1);
 		hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 0);
 		end_timing(c, stop);
@@ -611,7 +646,7 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	r = launch_trace(c, 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr);
 	if(r != ADYPT_OK) return r;
 	{
-		QueueArgs q = queue_args(c, 0, c->d_counters->count[0], c->d_counters->count[1]);
+		QueueArgs q = queue_args(c, 0, c->d_counters->count[0], c->d_counters->count[1], 1);
 		hipEvent_t *stop = begin_timing(c, 1);
 		hipLaunchKernelGGL(k_viewer, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, viewer_type);
 		end_timing(c, stop);
@@ -644,7 +679,6 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 	HIP_TRY(c, hipSetDevice(c->device));
 	SceneArgs sc; PixelArgs px;
 	fill_scene(c, &sc); fill_pixels(c, &px);
-	const int grid_c = (int)(c->capacity / kShadeThreads); // kNumSegments x chunks per segment
 	const bool stats = (c->instrumentation & 2) != 0;
 	for(int remaining = n_spp; remaining > 0;)
 	{
@@ -679,12 +713,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			// Sobol::Next (src/Util/Sobol.cpp:16-21) for the m frames of the batch
 			const int slot = c->sobol_next;
 			c->sobol_next = (slot + 1) % adypt_ctx::kSobolSlots;
-			if(!c->h_sobol[slot])
-			{
-				HIP_TRY(c, hipHostMalloc((void **)&c->h_sobol[slot], (size_t)kMaxFramesInFlight * 64 * sizeof(float), hipHostMallocDefault));
-				HIP_TRY(c, hipEventCreateWithFlags(&c->sobol_done[slot], hipEventDisableTiming));
-			}
-			else HIP_TRY(c, hipEventSynchronize(c->sobol_done[slot])); // the copy that last used this slot has left it
+			HIP_TRY(c, hipEventSynchronize(c->sobol_done[slot])); // the copy that last used this slot has left it
 			std::vector<float> pts((size_t)m * 2 * max_bounce);
 			int r = adypt_sobol_points(2 * max_bounce, c->spp, m, pts.data());
 			if(r != ADYPT_OK) return fail(c, r, adypt_host_last_error());
@@ -700,22 +729,24 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		{
 			// primary-only pass of the re-tracing frames: camera rays -> traversal -> cache image of each frame's group
 			f.n_frames = n_retrace; f.frame_first = first_retrace; f.frame_stride = life;
-			QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0]);
+			const int grid_r = (int)(kNumSegments * (pass_seg_paths(c, n_retrace) / kShadeThreads));
+			QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0], n_retrace);
 			hipEvent_t *stop = begin_timing(c, 1);
-			hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 1);
+			hipLaunchKernelGGL(k_gen_primary, dim3(grid_r), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 1);
 			end_timing(c, stop);
 			int r = launch_trace(c, 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, stats, nullptr);
 			if(r != ADYPT_OK) return r;
-			QueueArgs q2 = queue_args(c, 0, c->d_counters->count[0], c->d_counters->count[1]);
+			QueueArgs q2 = queue_args(c, 0, c->d_counters->count[0], c->d_counters->count[1], n_retrace);
 			stop = begin_timing(c, 1);
-			hipLaunchKernelGGL(k_store_cache, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, q2, px);
+			hipLaunchKernelGGL(k_store_cache, dim3(grid_r), dim3(kShadeThreads), 0, c->stream, f, q2, px);
 			end_timing(c, stop);
 			HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
 			f.frame_first = 0; f.frame_stride = 1;
 		}
 		f.n_frames = m;
+		const int grid_c = (int)(kNumSegments * (pass_seg_paths(c, m) / kShadeThreads)); // kNumSegments x chunks per segment of this batch
 		{
-			QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0]); // out = queue 0
+			QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0], m); // out = queue 0
 			hipEvent_t *stop = begin_timing(c, 1);
 			hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, use_cache, 1);
 			end_timing(c, stop);
@@ -728,7 +759,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 				int r = launch_trace(c, in, c->d_counters->count[b], c->d_counters->cursor[b], c->params.stack_size, stats, nullptr);
 				if(r != ADYPT_OK) return r;
 			}
-			QueueArgs q = queue_args(c, in, c->d_counters->count[b], c->d_counters->count[b + 1]);
+			QueueArgs q = queue_args(c, in, c->d_counters->count[b], c->d_counters->count[b + 1], m);
 			hipEvent_t *stop = begin_timing(c, 1);
 			hipLaunchKernelGGL(k_shade, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
 			end_timing(c, stop);
