@@ -84,9 +84,25 @@ __device__ inline void canon_sincos(float xf, float *s_out, float *c_out)
 	*c_out = (float)c;
 }
 
+// c / 255 for an 8-bit c (RG8 / RGB8 UNORM decoding): the correctly rounded binary32 quotients, folded at compile time.
+// A table load instead of the ~10-instruction IEEE division sequence — k_shade decodes 2 shift bytes per path and 12
+// texel channels per textured hit, and it is VALU-bound (profiles/: 74 % VALU busy).
+#define ADYPT_U8(i) ((float)(i) / 255.0f)
+#define ADYPT_U8x8(b) ADYPT_U8(b), ADYPT_U8(b + 1), ADYPT_U8(b + 2), ADYPT_U8(b + 3), ADYPT_U8(b + 4), ADYPT_U8(b + 5), ADYPT_U8(b + 6), ADYPT_U8(b + 7)
+#define ADYPT_U8x64(b) ADYPT_U8x8(b), ADYPT_U8x8(b + 8), ADYPT_U8x8(b + 16), ADYPT_U8x8(b + 24), ADYPT_U8x8(b + 32), ADYPT_U8x8(b + 40), ADYPT_U8x8(b + 48), ADYPT_U8x8(b + 56)
+__device__ const float kUnorm8[256] = {ADYPT_U8x64(0), ADYPT_U8x64(64), ADYPT_U8x64(128), ADYPT_U8x64(192)};
+#undef ADYPT_U8x64
+#undef ADYPT_U8x8
+#undef ADYPT_U8
+__device__ __forceinline__ float unorm8_to_float(uint32_t c) { return kUnorm8[c & 0xffu]; }
+
 __device__ inline float canon_pow(float xf, float yf)
 {
 	if(yf == 0.0f) return 1.0f;
+	// x^1 = x: the series below returns exactly x for every positive finite x (its double result is within 1e-15 of x,
+	// far inside the binary32 rounding interval; checked over the whole range by tests/test_oracle_golden.py), so the
+	// diffuse lobe's pow(1 - r.y, 1 / (0 + 1)) (pathtracer.glsl:58) costs nothing
+	if(yf == 1.0f && xf > 0.0f && xf < __uint_as_float(0x7f800000u)) return xf;
 	if(xf != xf || yf != yf) return xf + yf;
 	if(xf < 0.0f) return __uint_as_float(0x7fc00000u);
 	if(xf == 0.0f) return yf > 0.0f ? 0.0f : __uint_as_float(0x7f800000u);

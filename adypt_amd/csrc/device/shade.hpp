@@ -241,7 +241,7 @@ __device__ inline F3 sample_texture(const SceneArgs &sc, int tex, float s, float
 	const int i1 = i0 + 1 == w ? 0 : i0 + 1, j1 = j0 + 1 == h ? 0 : j0 + 1;
 	auto texel = [&](int i, int j) {
 		const uint32_t p = tx[(size_t)j * w + i];
-		return f3((float)(p & 0xffu) / 255.0f, (float)((p >> 8) & 0xffu) / 255.0f, (float)((p >> 16) & 0xffu) / 255.0f);
+		return f3(unorm8_to_float(p), unorm8_to_float(p >> 8), unorm8_to_float(p >> 16));
 	};
 	const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
 	F3 r = texel(i0, j0) * w00;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kShadeThreads, 6) void k_shade(FrameArgs f, SceneAr
 				if(illum0 < 6 && dot3(dir, normal) > 0) normal = -normal;
 
 				const uint8_t *sh = px.shift + (size_t)L * 2;
-				const Rng rng{(float)sh[0] / 255.0f, (float)sh[1] / 255.0f, sobol};
+				const Rng rng{unorm8_to_float(sh[0]), unorm8_to_float(sh[1]), sobol};
 				int illum = illum0;
 				bool done = false;
 				if(illum == 2)

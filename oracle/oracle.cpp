@@ -112,7 +112,15 @@ static void canon_sincos(float xf, float *s_out, float *c_out)
 	*c_out = (float)c;
 }
 
+static float canon_pow_series(float xf, float yf);
 static float canon_pow(float xf, float yf)
+{
+	// x^1 = x for positive finite x: what the series returns anyway (orc_pow_series lets the tests check that), spelled out
+	// so that the product may skip the series for the diffuse lobe
+	if(yf == 1.0f && xf > 0.0f && xf < INFINITY) return xf;
+	return canon_pow_series(xf, yf);
+}
+static float canon_pow_series(float xf, float yf)
 {
 	if(yf == 0.0f) return 1.0f;
 	if(xf != xf || yf != yf) return xf + yf;
@@ -736,6 +744,7 @@ ORC_API void orc_shift_bytes(uint32_t seed, int width, int height, uint8_t *out)
 
 ORC_API void orc_sincos(const float *x, int n, float *s, float *c) { for(int i = 0; i < n; ++i) canon_sincos(x[i], s + i, c + i); }
 ORC_API void orc_pow(const float *x, const float *y, int n, float *out) { for(int i = 0; i < n; ++i) out[i] = canon_pow(x[i], y[i]); }
+ORC_API void orc_pow_series(const float *x, const float *y, int n, float *out) { for(int i = 0; i < n; ++i) out[i] = canon_pow_series(x[i], y[i]); }
 
 // rays: n * 8 floats (ox, oy, oz, tmin, dx, dy, dz, unused)
 static void trace_batch(const OrcScene *sc, int stack_size, const float *rays, int64_t n, OrcHit *hits, int n_threads, bool any_hit)

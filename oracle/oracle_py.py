@@ -188,11 +188,12 @@ def sincos(x: np.ndarray):
     return s, c
 
 
-def pow_(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+def pow_(x: np.ndarray, y: np.ndarray, series_only: bool = False) -> np.ndarray:
+    """canonical pow; series_only skips the x^1 = x shortcut (lets the tests check that the series returns x there)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.ascontiguousarray(y, dtype=np.float32)
     out = np.empty_like(x)
-    lib().orc_pow(_p(x), _p(y), C.c_int(x.size), _p(out))
+    (lib().orc_pow_series if series_only else lib().orc_pow)(_p(x), _p(y), C.c_int(x.size), _p(out))
     return out
 
 
