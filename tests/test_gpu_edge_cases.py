@@ -124,3 +124,58 @@ def test_stack_spill_to_global_memory_is_bit_exact(lds_depth, scene_cache, sobol
     st = O.PathTracerState(c.width, c.height)
     O.pt_frames(osc, P, O.shift_bytes(3, c.width, c.height), sobol_matrices, st, 3)
     assert np.array_equal(bits(pt.ReadResult()), bits(st.accum[..., :3]))
+
+
+def test_c_abi_error_behaviour_on_the_device(tmp_path):
+    """SURVEY.md §8b 'Errors': every entry point returns 0 or a negative ADYPT_E_* and never crashes on misuse — null
+    handles / pointers, tracing before a camera is set, parameters outside their ranges, a device ordinal that does not
+    exist — and the context stays usable afterwards."""
+    import ctypes as C
+    from adypt_amd import _native as N
+    c = json.load(open(os.path.join(GOLDEN, "edge_cases.json")))["rand_25"]
+    obj = tmp_path / "s.obj"
+    obj.write_text(c["obj"])
+    sc = api.Scene()
+    assert sc.LoadFromFile(str(obj))
+    cfg = api.InstanceConfig()
+    b = api.WideBVH()
+    b.Build(sc, cfg.bvh_params())
+    hs = api.HipScene()
+    hs.Initialize(sc, b)
+    lib = N.lib
+    null = C.c_void_p()
+    # null context everywhere
+    buf = (C.c_float * 16)()
+    for call in (lambda: lib.adypt_trace_spp(null, 1), lambda: lib.adypt_trace_spp_async(null, 1), lambda: lib.adypt_wait(null),
+                 lambda: lib.adypt_trace_primary(null, 0), lambda: lib.adypt_reset(null), lambda: lib.adypt_get_spp(null),
+                 lambda: lib.adypt_read_radiance(null, buf), lambda: lib.adypt_read_display(null, buf), lambda: lib.adypt_reset_stats(null),
+                 lambda: lib.adypt_set_frames_in_flight(null, 2), lambda: lib.adypt_set_instrumentation(null, 1)):
+        assert call() == N.E_INVALID
+    lib.adypt_destroy(null)  # no-op
+    # a device that does not exist
+    pt = api.HipPathTracer()
+    with pytest.raises(N.AdyptError) as e:
+        pt.Initialize(cfg.pt_params(1), hs, 32, 32, device=63)
+    assert e.value.code == N.E_INVALID and "device" in str(e.value)
+    pt = api.HipPathTracer()
+    pt.Initialize(cfg.pt_params(1), hs, 40, 24)
+    ctx = pt._ctx
+    # tracing before the camera is set
+    assert lib.adypt_trace_spp(ctx, 1) == N.E_STATE and b"adypt_set_camera" in lib.adypt_last_error(ctx)
+    assert lib.adypt_trace_primary(ctx, 0) == N.E_STATE
+    # parameters outside their ranges are rejected and leave the active ones untouched
+    for field, value in (("stack_size", 0), ("stack_size", 65), ("max_bounce", 0), ("max_bounce", 33), ("subpixel", 0), ("tmp_lifetime", 0)):
+        p = cfg.pt_params(1)
+        setattr(p, field, value)
+        assert lib.adypt_set_params(ctx, C.byref(p)) == N.E_INVALID, field
+    assert lib.adypt_set_frames_in_flight(ctx, 0) == N.E_INVALID and lib.adypt_set_frames_in_flight(ctx, 100000) == N.E_INVALID
+    assert lib.adypt_trace_spp(ctx, -1) == N.E_INVALID
+    assert lib.adypt_read_radiance(ctx, None) == N.E_INVALID and lib.adypt_read_display(ctx, None) == N.E_INVALID
+    assert lib.adypt_trace_rays(ctx, None, 5, None, 0) == N.E_INVALID
+    assert lib.adypt_assemble_radiance(ctx, None, 0, None) == N.E_INVALID
+    # ... and the context still renders
+    ip, iv = api.camera_matrices(60.0, 10.0, 0.0, 40, 24)
+    pt.SetCamera(ip, iv, [0.1, 0.0, 3.0])
+    pt.Trace(True, 2)
+    assert pt.GetSPP() == 2 and np.isfinite(pt.ReadResult()).all()
+    assert lib.adypt_trace_spp(ctx, 0) == 0 and pt.GetSPP() == 2
