@@ -88,7 +88,11 @@ private:
 		p.subpixel = m_config->m_subpixel; p.tmp_lifetime = m_config->m_tmp_lifetime;
 		p.ray_tmin = m_config->m_ray_tmin; p.clamp = m_config->m_clamp;
 		p.sun[0] = m_config->m_sun.x; p.sun[1] = m_config->m_sun.y; p.sun[2] = m_config->m_sun.z;
+#ifdef ADYPT_BINDING_FIXED_SEED
+		p.shift_seed = ADYPT_BINDING_FIXED_SEED; // reproducible runs (tests); the reference seeds its shift image from std::random_device
+#else
 		p.shift_seed = std::random_device{}();
+#endif
 		return adypt_set_params(m_ctx, &p) == ADYPT_OK;
 	}
 
