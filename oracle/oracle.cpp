@@ -16,6 +16,9 @@
 //   * Woop / camera / Sobol / shift bytes are checked bit-for-bit against the reference's own CPU code
 //     compiled from /root/reference (oracle/_ref/adypt_ref) through the committed fixtures in tests/golden/.
 //   * The traversal is checked against an fp64 brute-force ray/triangle intersection on the fixtures.
+//   * PARITY UNPINNED for the shader half: the reference has no tests, ships no fixtures for this path, and its GLSL
+//     cannot be compiled or run here, so no output of the reference's traversal / Render pins this restatement; it is
+//     a line-by-line reading of the shaders, checked by fp64 brute force (traversal) and by construction (shading).
 //   * The GLSL shaders themselves cannot be compiled or run here (GL 4.5 + bindless textures, no GPU, no GL):
 //     GLSL leaves the rounding of normalize/dot/1/x/pow/sin/cos and fma contraction unspecified, so this file
 //     *defines* the canonical arithmetic both sides (oracle and HIP kernels) implement:
