@@ -330,6 +330,11 @@ class HipPathTracer:
                 self.m_viewer_type = ViewerTypes.kDiffuse
             N.check(N.lib.adypt_trace_primary(self._ctx, self.m_viewer_type), self._ctx)
 
+    def SetSunVisibility(self, enabled: bool, direction=None) -> None:
+        """The occlusion query the reference has commented out (pathtracer.glsl:132); off = the reference as it runs."""
+        d = None if direction is None else np.ascontiguousarray(direction, dtype=np.float32).reshape(3)
+        N.check(N.lib.adypt_set_sun_visibility(self._ctx, 1 if enabled else 0, None if d is None else d.ctypes.data), self._ctx)
+
     def TraceAsync(self, n_spp: int = 1) -> None:
         """Trace(true) n_spp times without waiting for the GPU (adypt_trace_spp_async); pair with Wait()."""
         self.m_viewer_type = ViewerTypes.kPTRadiance

@@ -2,7 +2,8 @@
 //   Instance::InitializeFromFile / Initialize (src/Instance.cpp:10-42,59-69) -> N x Trace(true) -> SaveResult
 //   (src/Tracer/OglPathTracer.cpp:199-212).  The interactive window / ImGui front-end is out of scope.
 //
-//   adypt_hip scene.config [--spp N] [--out result.exr] [--fp16] [--primary TYPE] [--preview file.png] [--seed S] [--device D]
+//   adypt_hip scene.config [--spp N] [--out result.exr] [--fp16] [--primary TYPE] [--preview file.png] [--sun-visibility] [--seed S] [--device D]
+//   --sun-visibility: enable the occlusion query the reference has commented out (pathtracer.glsl:132)
 //   --preview: what the reference shows in its window (shaders/screen.glsl), as PNG
 #include "adypt_hip.h"
 #include "adypt_host.h"
@@ -21,8 +22,8 @@ static double now_ms()
 
 int main(int argc, char **argv)
 {
-	if(argc < 2) { fprintf(stderr, "usage: %s scene.config [--spp N] [--out file.exr] [--fp16] [--primary TYPE] [--preview file.png] [--seed S] [--device D]\n", argv[0]); return 2; }
-	int spp = 64, fp16 = 0, primary = -1, device = 0;
+	if(argc < 2) { fprintf(stderr, "usage: %s scene.config [--spp N] [--out file.exr] [--fp16] [--primary TYPE] [--preview file.png] [--sun-visibility] [--seed S] [--device D]\n", argv[0]); return 2; }
+	int spp = 64, fp16 = 0, primary = -1, device = 0, sun_visibility = 0;
 	unsigned seed = 12345;
 	std::string out = "result.exr", preview;
 	for(int i = 2; i < argc; ++i)
@@ -32,6 +33,7 @@ int main(int argc, char **argv)
 		else if(a == "--out" && i + 1 < argc) out = argv[++i];
 		else if(a == "--preview" && i + 1 < argc) preview = argv[++i];
 		else if(a == "--fp16") fp16 = 1;
+		else if(a == "--sun-visibility") sun_visibility = 1;
 		else if(a == "--primary" && i + 1 < argc) primary = atoi(argv[++i]);
 		else if(a == "--seed" && i + 1 < argc) seed = (unsigned)strtoul(argv[++i], nullptr, 10);
 		else if(a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
@@ -74,6 +76,7 @@ int main(int argc, char **argv)
 	float ip[16], iv[16];
 	adypt_camera_matrices(cfg.fov, cfg.yaw, cfg.pitch, cfg.width, cfg.height, ip, iv);
 	if(adypt_set_params(ctx, &p) != ADYPT_OK || adypt_set_camera(ctx, cfg.position, ip, iv) != ADYPT_OK) { fprintf(stderr, "[TRACER]Err: %s\n", adypt_last_error(ctx)); return 1; }
+	if(sun_visibility && adypt_set_sun_visibility(ctx, 1, nullptr) != ADYPT_OK) { fprintf(stderr, "[TRACER]Err: %s\n", adypt_last_error(ctx)); return 1; }
 	adypt_set_instrumentation(ctx, 1);
 	double t0 = now_ms();
 	int r = primary >= 0 ? adypt_trace_primary(ctx, primary) : adypt_trace_spp(ctx, spp);

@@ -98,6 +98,16 @@ struct QueueArgs {
 	                               //   than fit still spreads evenly over the 8 segments, and the grids cover seg_paths only
 };
 
+// Optional sun-visibility test = the occlusion query the reference has commented out (pathtracer.glsl:132): escaped
+// paths go to this queue instead of receiving the sun term at once; an any-hit traversal and k_shadow_resolve follow.
+struct ShadowArgs {
+	float4 *o, *d, *col;           // (origin, tmin), (normalised sun direction, bits(path)), (throughput, radiance parked?)
+	float4 *hit;                   // any-hit result per slot
+	uint32_t *count;               // [s * kCursorStride] escaped paths per segment of this bounce
+	float dir[3];
+	int32_t enabled;
+};
+
 struct PixelArgs {
 	float4 *accum;                 // running mean RGBA per local pixel   (image 0)
 	float4 *cache;                 // cached primary hit per local pixel  (image 1)
@@ -318,7 +328,7 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 
 // One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for every live path.
 // store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
-__global__ __launch_bounds__(kShadeThreads, 6) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int b, int store_cache, int count_stats)
+__global__ __launch_bounds__(kShadeThreads, 6) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, ShadowArgs sh, int b, int store_cache, int count_stats)
 {
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	const uint32_t n_in = q.count_in[seg * kCursorStride];
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(kShadeThreads, 6) void k_shade(FrameArgs f, SceneAr
 	F3 origin = f3(0, 0, 0), dir = f3(0, 0, 1), color = f3(0, 0, 0), ret = f3(0, 0, 0);
 	int L = 0, pi = 0;
 	const float *sobol = f.sobol;
-	bool shaded = false, bad_mat = false, parked = false;
+	bool shaded = false, bad_mat = false, parked = false, escaped = false;
 	F3 ret_in = f3(0, 0, 0);
 	if(alive)
 	{
@@ -355,7 +365,8 @@ __global__ __launch_bounds__(kShadeThreads, 6) void k_shade(FrameArgs f, SceneAr
 
 		if(tri_idx == -1)
 		{
-			ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret);
+			if(sh.enabled) escaped = true; // the sun term waits for the visibility query (k_shadow_resolve)
+			else ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret);
 			alive = false;
 		}
 		else
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(kShadeThreads, 6) void k_shade(FrameArgs f, SceneAr
 				if(b + 1 >= f.max_bounce) alive = false; // last loop iteration
 			}
 		}
-		if(!alive) finish_path(f, px, pi, L, ret);
+		if(!alive && !escaped) finish_path(f, px, pi, L, ret);
 	}
 	// statistics.  The FetchInfo count is only collected in instrumented runs, one atomic per workgroup: per-wave atomics
 	// on a single word (23 k per launch) cost ~0.27 ms on this chip (~88 same-address atomics/us) — 75 % of this kernel.
@@ -471,6 +482,35 @@ __global__ __launch_bounds__(kShadeThreads, 6) void k_shade(FrameArgs f, SceneAr
 		}
 		q.out_col[slot] = make_float4(color.x, color.y, color.z, parked ? 1.0f : 0.0f);
 	}
+	if(sh.enabled) // (kernel argument: uniform branch around the barriers of append_slot)
+	{
+		const uint32_t sslot = append_slot(escaped, sh.count + seg * kCursorStride, seg * q.seg_cap);
+		if(escaped)
+		{
+			const float4 ro = q.ray_o[slot_in]; // the position the path escaped from (camera or last hit), tmin
+			sh.o[sslot] = ro;
+			sh.d[sslot] = make_float4(sh.dir[0], sh.dir[1], sh.dir[2], __int_as_float(pi));
+			sh.col[sslot] = make_float4(color.x, color.y, color.z, parked ? 1.0f : 0.0f);
+		}
+	}
+}
+
+// pathtracer.glsl:130-135 with the commented-out condition enabled: the escaped path receives the sun term only if the
+// any-hit query towards the sun found nothing; then main()'s clamp + accumulate (:224-226)
+__global__ __launch_bounds__(kShadeThreads) void k_shadow_resolve(FrameArgs f, QueueArgs q, PixelArgs px, ShadowArgs sh)
+{
+	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
+	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
+	if(local >= sh.count[seg * kCursorStride]) return;
+	const uint32_t slot = seg * q.seg_cap + local;
+	const float4 c4 = sh.col[slot];
+	const int pi = __float_as_int(sh.d[slot].w);
+	int L = pi;
+	if(f.n_frames > 1) L = pi - (int)((uint32_t)pi / (uint32_t)f.n_local_px) * f.n_local_px;
+	F3 ret = f3(0, 0, 0);
+	if(c4.w != 0.0f) { const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); }
+	if(__float_as_int(sh.hit[slot].x) == -1) ret = fma3(f3(c4.x, c4.y, c4.z), f3(f.sun[0], f.sun[1], f.sun[2]), ret);
+	finish_path(f, px, pi, L, ret);
 }
 
 // primaryray.glsl main (:46-94): colour the primary hit by viewer type; also records the hit in the cache image

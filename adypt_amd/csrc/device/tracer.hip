@@ -26,6 +26,8 @@ constexpr int kMaxFramesInFlight = 128;
 struct FrameCounters {                 // one memset per frame; every counter on its own 128-byte line
 	uint32_t count[kMaxBounce + 1][kNumSegments * kCursorStride];   // live rays per queue segment after bounce b
 	uint32_t cursor[kMaxBounce + 1][kNumSegments * kCursorStride];  // traversal fetch cursors per segment
+	uint32_t sh_count[kMaxBounce + 1][kNumSegments * kCursorStride];  // sun-visibility queries per segment of bounce b
+	uint32_t sh_cursor[kMaxBounce + 1][kNumSegments * kCursorStride];
 };
 
 thread_local std::string g_create_error;
@@ -61,6 +63,9 @@ struct adypt_ctx {
 	uint32_t seg_cap = 0;      // slots per XCD-affine segment (multiple of kShadeThreads)
 	float4 *q_o[2] = {nullptr, nullptr}, *q_d[2] = {nullptr, nullptr}, *q_col[2] = {nullptr, nullptr};
 	float4 *d_hit = nullptr;
+	float4 *sh_o = nullptr, *sh_d = nullptr, *sh_col = nullptr, *sh_hit = nullptr; // sun-visibility queue (allocated when enabled)
+	int sun_visibility = 0;
+	float sun_dir[3] = {0.6f, 1.0f, 0.2f}; // normalised at the time it is set
 	float4 *d_done = nullptr;  // [frames_in_flight][local pixels] finished samples of a multi-frame batch
 	float *d_sobol = nullptr;  // [kMaxFramesInFlight][64] Sobol points of the frames of the current batch
 	// pinned staging of the Sobol points, one slot per batch in flight on the stream: the upload is then a true
@@ -224,14 +229,15 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	return ensure_spill(c, stack_size);
 }
 
-int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *cursor, int stack_size, bool stats, RayStats *ray_stats, bool any_hit = false)
+int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *cursor, int stack_size, bool stats, RayStats *ray_stats, bool any_hit = false,
+				 bool shadow_queue = false)
 {
 	TraceArgs a;
 	a.nodes = (const uint4 *)c->d_nodes;
 	a.woop = (const float4 *)c->d_woop;
 	a.tri_indices = (const int32_t *)c->d_tri_indices;
-	a.ray_o = c->q_o[parity]; a.ray_d = c->q_d[parity];
-	a.hit = c->d_hit;
+	a.ray_o = shadow_queue ? c->sh_o : c->q_o[parity]; a.ray_d = shadow_queue ? c->sh_d : c->q_d[parity];
+	a.hit = shadow_queue ? c->sh_hit : c->d_hit;
 	a.ray_stats = ray_stats;
 	a.count = count; a.cursor = cursor;
 	a.spill = c->d_spill;
@@ -332,9 +338,11 @@ int load_shift(adypt_ctx *c)
 // (re)allocate the wavefront queues for `fif` frames in flight: capacity = fif x local pixels, cut into 8 segments
 int alloc_queues(adypt_ctx *c, int fif)
 {
-	void *old[] = {c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->d_hit, c->d_done, c->d_ray_stats};
+	void *old[] = {c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->d_hit, c->d_done, c->d_ray_stats,
+				   c->sh_o, c->sh_d, c->sh_col, c->sh_hit};
 	for(void *b : old) if(b) (void)hipFree(b);
 	c->q_o[0] = c->q_o[1] = c->q_d[0] = c->q_d[1] = c->q_col[0] = c->q_col[1] = c->d_hit = c->d_done = nullptr;
+	c->sh_o = c->sh_d = c->sh_col = c->sh_hit = nullptr; // re-created by ensure_shadow_queue when the option is on
 	c->d_ray_stats = nullptr;
 	const size_t npx = (size_t)std::max(c->n_local_px, 64);
 	const size_t paths = npx * (size_t)fif;
@@ -352,6 +360,18 @@ int alloc_queues(adypt_ctx *c, int fif)
 	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_hit, nq * sizeof(float4)));
 	HIP_TRY(c, hipMalloc((void **)&c->d_done, paths * sizeof(float4))); // finished samples of a batch / parked radiance of live paths
+	return ADYPT_OK;
+}
+
+int ensure_shadow_queue(adypt_ctx *c)
+{
+	if(c->sh_o) return ADYPT_OK;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	const size_t nq = (size_t)c->capacity;
+	HIP_TRY(c, hipMalloc((void **)&c->sh_o, nq * sizeof(float4)));
+	HIP_TRY(c, hipMalloc((void **)&c->sh_d, nq * sizeof(float4)));
+	HIP_TRY(c, hipMalloc((void **)&c->sh_col, nq * sizeof(float4)));
+	HIP_TRY(c, hipMalloc((void **)&c->sh_hit, nq * sizeof(float4)));
 	return ADYPT_OK;
 }
 
@@ -545,7 +565,7 @@ void adypt_destroy(adypt_ctx *c)
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	for(EventPair &p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-	void *bufs[] = {c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
+	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
 					c->d_accum, c->d_cache, c->d_cache_next, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
 					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol};
 	for(void *b : bufs) if(b) (void)hipFree(b);
@@ -608,6 +628,21 @@ int adypt_set_instrumentation(adypt_ctx *c, int flags)
 			c->free_events.push_back(p);
 		}
 	}
+	return ADYPT_OK;
+}
+
+int adypt_set_sun_visibility(adypt_ctx *c, int enabled, const float dir[3])
+{
+	if(!c) return ADYPT_E_INVALID;
+	float d[3] = {0.6f, 1.0f, 0.2f}; // the direction of the reference's commented-out query (pathtracer.glsl:132)
+	if(dir) memcpy(d, dir, sizeof(d));
+	const float len2 = fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0]));
+	if(!(len2 > 0.0f) || !(len2 < INFINITY)) return fail(c, ADYPT_E_INVALID, "adypt_set_sun_visibility: direction must be finite and non-zero");
+	const float inv = 1.0f / sqrtf(len2); // normalize() in the canonical arithmetic (canon_math.hpp normalize3)
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	c->sun_dir[0] = d[0] * inv; c->sun_dir[1] = d[1] * inv; c->sun_dir[2] = d[2] * inv;
+	c->sun_visibility = enabled ? 1 : 0;
 	return ADYPT_OK;
 }
 
@@ -707,6 +742,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			if(r != ADYPT_OK) return r;
 			fill_pixels(c, &px);
 		}
+		if(c->sun_visibility) { int r = ensure_shadow_queue(c); if(r != ADYPT_OK) return r; }
 		FrameArgs f;
 		fill_frame(c, &f);
 		{
@@ -760,9 +796,23 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 				if(r != ADYPT_OK) return r;
 			}
 			QueueArgs q = queue_args(c, in, c->d_counters->count[b], c->d_counters->count[b + 1], m);
+			ShadowArgs sh;
+			sh.o = c->sh_o; sh.d = c->sh_d; sh.col = c->sh_col; sh.hit = c->sh_hit;
+			sh.count = c->d_counters->sh_count[b];
+			memcpy(sh.dir, c->sun_dir, sizeof(sh.dir));
+			sh.enabled = c->sun_visibility;
 			hipEvent_t *stop = begin_timing(c, 1);
-			hipLaunchKernelGGL(k_shade, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
+			hipLaunchKernelGGL(k_shade, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, sh, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
 			end_timing(c, stop);
+			if(c->sun_visibility)
+			{
+				// the escaped paths of this bounce: any-hit query towards the sun, then sun term + accumulate (pathtracer.glsl:130-135)
+				int r = launch_trace(c, 0, c->d_counters->sh_count[b], c->d_counters->sh_cursor[b], c->params.stack_size, stats, nullptr, true, true);
+				if(r != ADYPT_OK) return r;
+				stop = begin_timing(c, 1);
+				hipLaunchKernelGGL(k_shadow_resolve, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, q, px, sh);
+				end_timing(c, stop);
+			}
 		}
 		if(m > 1)
 		{

@@ -122,6 +122,11 @@ int adypt_trace_spp(adypt_ctx *ctx, int n_spp);
  * (stack overflow, HIP errors).  Every other entry point that reads results synchronises by itself. */
 int adypt_trace_spp_async(adypt_ctx *ctx, int n_spp);
 int adypt_wait(adypt_ctx *ctx);
+/* SURVEY.md §8 f1, off by default (= the reference as it runs): enables the occlusion query the reference has commented
+ * out in Render (shaders/pathtracer.glsl:132, `if(!BVHIntersection(origin, normalize(vec3(0.6, 1, 0.2))))`): a path that
+ * leaves the scene receives the sun term only if an any-hit ray (traversal.glsl:257-494) from its last position towards
+ * `dir` (NULL = the reference's (0.6, 1, 0.2); normalised here) finds nothing.  Takes effect for the frames traced next. */
+int adypt_set_sun_visibility(adypt_ctx *ctx, int enabled, const float dir[3]);
 int adypt_reset(adypt_ctx *ctx);
 int adypt_get_spp(const adypt_ctx *ctx); /* OglPathTracer::GetSPP */
 /* How many consecutive frames adypt_trace_spp traces as one wavefront pass (1..128).  Frames are independent

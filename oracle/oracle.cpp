@@ -222,6 +222,10 @@ struct OrcParams
 	int32_t width, height, stack_size, max_bounce, subpixel, tmp_life;
 	float tmin, clamp, sun[3], origin[3];
 	float inv_proj[16], inv_view[16]; // column-major like glm
+	// the occlusion test the reference has commented out (pathtracer.glsl:132): when a path escapes, the sun term is
+	// only added if an any-hit ray from the last position towards normalize(sun_dir) finds nothing.  0 = reference behaviour.
+	int32_t sun_visibility;
+	float sun_dir[3];
 };
 struct OrcHit { int32_t ref_idx, tri_id; float u, v, t; uint32_t nodes, tris, hash, max_depth; };
 struct OrcStats { uint64_t rays, nodes, tris, hits, shaded, texel_fetches, stack_overflows; uint32_t max_depth; uint32_t pad; };
@@ -513,7 +517,21 @@ static V3 render(const OrcScene &sc, const OrcParams &p, int spp, V3 dir, const 
 		}
 		else { tri_idx = *cache_tri; tu = cache_uv[0]; tv = cache_uv[1]; }
 
-		if(tri_idx == -1) { ret = fma3(color, sun, ret); break; }
+		if(tri_idx == -1)
+		{
+			bool lit = true;
+			if(p.sun_visibility) // if(!BVHIntersection(origin, normalize(vec3(0.6, 1, 0.2))))   (pathtracer.glsl:132)
+			{
+				OrcHit sh;
+				bvh_intersect(sc, p.stack_size, o4, normalize3(v3(p.sun_dir[0], p.sun_dir[1], p.sun_dir[2])), &sh, true);
+				++cn.rays; cn.nodes += sh.nodes; cn.tris += sh.tris;
+				if(sh.max_depth == 0xffffffffu) ++cn.overflows; else if(sh.max_depth > cn.max_depth) cn.max_depth = sh.max_depth;
+				if(sh.tri_id != -1) ++cn.hits;
+				lit = sh.tri_id == -1;
+			}
+			if(lit) ret = fma3(color, sun, ret);
+			break;
+		}
 
 		Surface s;
 		if(!fetch_info(sc, tri_idx, tu, tv, &s, cn)) break;

@@ -41,7 +41,7 @@ class _Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("stack_size", C.c_int32), ("max_bounce", C.c_int32),
                 ("subpixel", C.c_int32), ("tmp_life", C.c_int32), ("tmin", C.c_float), ("clamp", C.c_float),
                 ("sun", C.c_float * 3), ("origin", C.c_float * 3), ("inv_proj", C.c_float * 16),
-                ("inv_view", C.c_float * 16)]
+                ("inv_view", C.c_float * 16), ("sun_visibility", C.c_int32), ("sun_dir", C.c_float * 3)]
 
 
 class Stats(C.Structure):
@@ -130,11 +130,13 @@ class Scene:
 
 
 def make_params(width, height, origin, inv_proj, inv_view, *, stack_size=24, max_bounce=8, subpixel=8, tmp_life=16,
-                tmin=1e-4, clamp=4.0, sun=(12.0, 11.0, 10.0)) -> _Params:
+                tmin=1e-4, clamp=4.0, sun=(12.0, 11.0, 10.0), sun_visibility=False, sun_dir=(0.6, 1.0, 0.2)) -> _Params:
     p = _Params()
     p.width, p.height, p.stack_size, p.max_bounce, p.subpixel, p.tmp_life = width, height, stack_size, max_bounce, subpixel, tmp_life
     p.tmin, p.clamp = tmin, clamp
     p.sun[:] = [float(x) for x in sun]
+    p.sun_visibility = 1 if sun_visibility else 0
+    p.sun_dir[:] = [float(x) for x in sun_dir]
     p.origin[:] = [float(x) for x in origin]
     p.inv_proj[:] = [float(x) for x in np.asarray(inv_proj, dtype=np.float32).reshape(16)]
     p.inv_view[:] = [float(x) for x in np.asarray(inv_view, dtype=np.float32).reshape(16)]

@@ -179,3 +179,40 @@ def test_c_abi_error_behaviour_on_the_device(tmp_path):
     pt.Trace(True, 2)
     assert pt.GetSPP() == 2 and np.isfinite(pt.ReadResult()).all()
     assert lib.adypt_trace_spp(ctx, 0) == 0 and pt.GetSPP() == 2
+
+
+@pytest.mark.parametrize("name,w,h,fif", [("tiny0", 96, 64, 1), ("tiny0", 100, 75, 5), ("sponza", 192, 108, 32), ("sibenik", 160, 90, 3)])
+def test_sun_visibility_option_matches_oracle(name, w, h, fif, scene_cache, sobol_matrices):
+    """the occlusion query the reference has commented out (pathtracer.glsl:132) as an option — escaped
+    paths receive the sun term only if an any-hit ray towards the sun finds nothing.  Bit-exact against the oracle with the
+    same option, for single frames and batches; the shadow rays are counted as rays; off = unchanged."""
+    from adypt_amd import scenes
+    spec = scenes.make_scene(name, scene_cache, width=w, height=h, pt={"maxBounce": 5, "stackSize": 24, "tmpLifetime": 3})
+    inst = api.Instance()
+    assert inst.InitializeFromFile(spec.config_path, shift_seed=21)
+    pt, c = inst.m_path_tracer, inst.m_config.c
+    osc = O.Scene(inst.bvh.nodes, inst.bvh.tri_indices, inst.scene.triangles, inst.scene.materials, textures=inst.scene.textures)
+    ip, iv = O.camera(c.fov, c.yaw, c.pitch, c.width, c.height)
+    common = dict(stack_size=c.stack_size, max_bounce=c.max_bounce, subpixel=c.subpixel, tmp_life=c.tmp_lifetime, tmin=c.ray_tmin,
+                  clamp=c.clamp, sun=list(c.sun))
+    pt.SetFramesInFlight(fif)
+    pt.SetInstrumentation(counters=True)
+    results = {}
+    for label, direction in (("off", None), ("default", None), ("custom", [-0.3, 0.8, 0.5])):
+        on = label != "off"
+        pt.SetSunVisibility(on, direction)
+        pt.Reset()
+        pt.ResetStats()
+        pt.Trace(True, 7)
+        img, g = pt.ReadResult(), pt.GetStats()
+        P = O.make_params(c.width, c.height, list(c.position), ip, iv, sun_visibility=on,
+                          sun_dir=direction if direction is not None else (0.6, 1.0, 0.2), **common)
+        st = O.PathTracerState(c.width, c.height)
+        ost = O.pt_frames(osc, P, O.shift_bytes(21, c.width, c.height), sobol_matrices, st, 7).as_dict()
+        assert np.array_equal(bits(img), bits(st.accum[..., :3])), label
+        assert (g["rays"], g["nodes_visited"], g["tris_tested"], g["hits"], g["shaded"]) == (ost["rays"], ost["nodes"], ost["tris"], ost["hits"], ost["shaded"]), label
+        results[label] = (img, g["rays"])
+    assert results["default"][1] >= results["off"][1]                       # the queries are rays
+    assert (results["default"][0] <= results["off"][0]).all()               # occlusion only removes light
+    with pytest.raises(Exception):
+        pt.SetSunVisibility(True, [0.0, 0.0, 0.0])

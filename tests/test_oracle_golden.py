@@ -173,3 +173,24 @@ def test_pow_of_exponent_one_is_the_identity_in_the_canonical_series():
     bad = np.array([-1.0, -0.0, 0.0, np.inf, np.nan], np.float32)
     a, b = O.pow_(bad, np.ones_like(bad)), O.pow_(bad, np.ones_like(bad), series_only=True)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_sun_visibility_option_of_the_oracle(sobol_matrices):
+    """The occlusion query the reference has commented out (pathtracer.glsl:132) as an option of the restatement: off is the
+    reference as it runs (the committed golden frame), on only ever removes sun light and traces extra (any-hit) rays."""
+    from tests.helpers import oracle_scene_from_golden
+    import json
+    sc = oracle_scene_from_golden("tiny0")
+    cam = np.load(os.path.join(GOLDEN, "tiny0_kat.npz"))["cam"]
+    ip, iv = O.camera(float(cam[0]), float(cam[1]), float(cam[2]), 32, 18)
+    kw = dict(stack_size=16, max_bounce=5, subpixel=2, tmp_life=2, tmin=1e-4, clamp=4.0, sun=[12.0, 11.0, 10.0])
+    imgs, rays = {}, {}
+    for on in (False, True):
+        P = O.make_params(32, 18, [float(x) for x in cam[3:6]], ip, iv, sun_visibility=on, **kw)
+        st = O.PathTracerState(32, 18)
+        s = O.pt_frames(sc, P, O.shift_bytes(4242, 32, 18), sobol_matrices, st, 4).as_dict()
+        imgs[on], rays[on] = st.accum.copy(), s["rays"]
+    ref = np.load(os.path.join(GOLDEN, "tiny0_frame_32x18_4spp.npy"))
+    assert np.array_equal(imgs[False].view(np.uint32), ref.view(np.uint32))
+    assert rays[True] > rays[False] and (imgs[True][..., :3] <= imgs[False][..., :3]).all()
+    assert (imgs[True][..., :3] < imgs[False][..., :3]).any()
