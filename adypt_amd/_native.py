@@ -113,6 +113,7 @@ _SIGS = {
     "adypt_config_json": (C.c_size_t, [C.POINTER(Config), C.c_char_p, C.c_size_t]),
     "adypt_config_save": (C.c_int, [C.c_char_p, C.POINTER(Config)]),
     "adypt_host_last_error": (C.c_char_p, []),
+    "adypt_camera_control": (None, [C.POINTER(Config), C.c_uint32, C.c_float, C.c_float, C.c_float]),
     "adypt_scene_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "adypt_scene_free": (None, [C.c_void_p]),
     "adypt_scene_triangles": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p)]),

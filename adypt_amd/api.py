@@ -244,7 +244,7 @@ def load_exr(path: str) -> np.ndarray:
 
 
 class Camera:
-    """Camera::Initialize / GetView / GetProjection (src/Tracer/Camera.hpp:27-36); Control() is out of scope."""
+    """Camera::Initialize / GetView / GetProjection / Control (src/Tracer/Camera.hpp:14-37)."""
 
     def Initialize(self, cfg: InstanceConfig, width: int, height: int) -> None:
         self.cfg, self.width, self.height = cfg, width, height
@@ -259,6 +259,12 @@ class Camera:
     @property
     def position(self) -> np.ndarray:
         return np.array(list(self.cfg.c.position), dtype=np.float32)
+
+    KEY_W, KEY_A, KEY_S, KEY_D, KEY_SPACE, KEY_LEFT_SHIFT = 1, 2, 4, 8, 16, 32
+
+    def Control(self, keys: int = 0, mouse_dx: float = 0.0, mouse_dy: float = 0.0, frame_seconds: float = 0.0) -> None:
+        """Camera::Control (src/Tracer/Camera.cpp:25-59) with the key / mouse state passed in instead of read from GLFW."""
+        N.lib.adypt_camera_control(C.byref(self.cfg.c), keys, mouse_dx, mouse_dy, frame_seconds)
 
 
 def camera_matrices(fov: float, yaw: float, pitch: float, width: int, height: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -465,5 +471,12 @@ class Instance:
         self.m_valid = True
         return True
 
-    def Update(self, enable_pt: bool, n_spp: int = 1) -> None:
+    def Update(self, enable_pt: bool, n_spp: int = 1, keys: int = 0, mouse: Tuple[float, float] = (0.0, 0.0),
+               frame_seconds: float = 0.0) -> None:
+        """Instance::Update (src/Instance.cpp:44-57) without the window: while not path tracing the camera follows the input
+        state (Camera::Control) and is handed to the tracer, then one Trace(enable_pt)."""
+        if not enable_pt:
+            self.m_camera.Control(keys, mouse[0], mouse[1], frame_seconds)
+            ip, iv = self.m_camera.matrices()
+            self.m_path_tracer.SetCamera(ip, iv, self.m_camera.position)
         self.m_path_tracer.Trace(enable_pt, n_spp)

@@ -394,6 +394,32 @@ int adypt_save_png(const char *path, const uint8_t *rgba8, int width, int height
 	return os.good() ? ADYPT_OK : ADYPT_E_IO;
 }
 
+// Camera::Control (src/Tracer/Camera.cpp:25-59) + move_forward (Camera.hpp:19-24), driven by explicit input state
+void adypt_camera_control(adypt_config *cfg, uint32_t keys, float mouse_dx, float mouse_dy, float frame_seconds)
+{
+	if(!cfg) return;
+	const float kDeg = 0.01745329251994329576923690768489f; // glm::radians
+	const float speed = frame_seconds * cfg->speed;
+	auto move_forward = [&](float dist, float dir) {
+		const float rad = kDeg * (cfg->yaw + dir);
+		cfg->position[0] -= std::sin(rad) * dist;
+		cfg->position[2] -= std::cos(rad) * dist;
+	};
+	if(keys & ADYPT_KEY_W) move_forward(speed, 0.0f);
+	if(keys & ADYPT_KEY_A) move_forward(speed, 90.0f);
+	if(keys & ADYPT_KEY_D) move_forward(speed, -90.0f);
+	if(keys & ADYPT_KEY_S) move_forward(speed, 180.0f);
+	if(keys & ADYPT_KEY_SPACE) cfg->position[1] += speed;
+	if(keys & ADYPT_KEY_LEFT_SHIFT) cfg->position[1] -= speed;
+	if(mouse_dx != 0.0f || mouse_dy != 0.0f)
+	{
+		cfg->yaw -= mouse_dx * cfg->mouse_sensitive;
+		cfg->pitch -= mouse_dy * cfg->mouse_sensitive;
+		cfg->pitch = fmin_glm(fmax_glm(cfg->pitch, -90.0f), 90.0f);          // glm::clamp = min(max(x, lo), hi)
+		cfg->yaw = cfg->yaw - 360.0f * std::floor(cfg->yaw / 360.0f);         // glm::mod(x, y) = x - y * floor(x / y)
+	}
+}
+
 int adypt_sobol_points(int dim, int first, int n, float *out)
 {
 	if(dim < 0 || dim > 64 || first < 0 || n < 0 || !out) { set_host_error("adypt_sobol_points: dim must be <= 64"); return ADYPT_E_INVALID; }

@@ -39,6 +39,14 @@ size_t adypt_config_json(const adypt_config *cfg, char *buf, size_t cap);
 int adypt_config_save(const char *path, const adypt_config *cfg);   /* InstanceConfig::SaveToFile */
 const char *adypt_host_last_error(void);
 
+/* Camera::Control (src/Tracer/Camera.cpp:25-59) without the window: the key / mouse state GLFW and ImGui would report is
+ * passed in.  keys: ADYPT_KEY_* bits held this frame; mouse_dx/dy: cursor movement in pixels while the left button is
+ * held (0 otherwise); frame_seconds: fps.GetDelta().  Same arithmetic: move = frame_seconds * speed along yaw (+90 / -90 /
+ * 180 degrees for A / D / S), space / shift move along y, yaw -= dx * sensitivity (mod 360), pitch -= dy * sensitivity
+ * clamped to [-90, 90]. */
+enum { ADYPT_KEY_W = 1, ADYPT_KEY_A = 2, ADYPT_KEY_S = 4, ADYPT_KEY_D = 8, ADYPT_KEY_SPACE = 16, ADYPT_KEY_LEFT_SHIFT = 32 };
+void adypt_camera_control(adypt_config *cfg, uint32_t keys, float mouse_dx, float mouse_dy, float frame_seconds);
+
 /* ---- Scene (src/Util/Scene.cpp:9-136) + material/texture conversion (src/Tracer/OglScene.cpp:12-91) ------------- */
 typedef struct adypt_scene adypt_scene;
 int adypt_scene_load(const char *obj_path, adypt_scene **out);      /* Scene::LoadFromFile + init_materials */

@@ -239,6 +239,26 @@ def test_async_enqueue_of_several_contexts_from_one_thread(scene_cache):
     assert e.value.code == N.E_STACK_OVERFLOW
 
 
+def test_instance_update_loop_without_a_window(scene_cache, sobol_matrices):
+    """Instance::Update (src/Instance.cpp:44-57) driven by explicit input state: viewer frames follow the moving camera
+    (Camera::Control -> SetCamera -> Trace(false)), then path tracing starts from where the camera stopped."""
+    inst = make_instance(scene_cache, "tiny0", 96, 64, seed=8, pt={"maxBounce": 4})
+    K = api.Camera
+    start = np.array(list(inst.m_config.c.position), dtype=np.float32)
+    for _ in range(3):
+        inst.Update(False, keys=K.KEY_W | K.KEY_A | K.KEY_SPACE, mouse=(6.0, -4.0), frame_seconds=0.125)
+    c = inst.m_config.c
+    assert not np.array_equal(np.array(list(c.position), dtype=np.float32), start)
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)   # the config now holds the moved camera
+    rgba, _, _ = O.primary_frame(osc, P, 0)
+    assert np.array_equal(bits(inst.m_path_tracer.ReadResult()), bits(rgba[..., :3]))
+    inst.Update(True, 4)
+    st = O.PathTracerState(c.width, c.height)
+    O.pt_frames(osc, P, O.shift_bytes(8, c.width, c.height), sobol_matrices, st, 4)
+    assert np.array_equal(bits(inst.m_path_tracer.ReadResult()), bits(st.accum[..., :3]))
+    assert inst.m_path_tracer.GetSPP() == 4
+
+
 def test_full_size_frame_bit_exact_and_deterministic(scene_cache, sobol_matrices):
     """BASELINE config 2/3 size (1920x1080, sponza stand-in, 8 bounces): primary hits and one path-traced frame equal
     the oracle pixel for pixel; re-running gives identical bits; rays are counted exactly."""

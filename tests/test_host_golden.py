@@ -143,6 +143,33 @@ def test_degenerate_tiny_scenes_build_like_the_reference(tmp_path):
         assert len(b.tri_indices) >= sc.n_tris
 
 
+def test_camera_control_arithmetic():
+    """Camera::Control / move_forward (src/Tracer/Camera.cpp:25-59, Camera.hpp:19-24) with explicit input state: WASD move in
+    the yaw plane, space / shift along y, the mouse turns (yaw mod 360, pitch clamped to +-90)."""
+    cfg = api.InstanceConfig()
+    c = cfg.c
+    c.speed, c.mouse_sensitive, c.yaw, c.pitch = 2.0, 0.5, 30.0, 10.0
+    c.position[:] = [1.0, 2.0, 3.0]
+    cam = api.Camera()
+    cam.Initialize(cfg, 64, 36)
+    f32 = np.float32
+    cam.Control(api.Camera.KEY_W | api.Camera.KEY_SPACE, frame_seconds=0.25)
+    dist = f32(0.25) * f32(2.0)
+    rad = f32(0.017453292519943295) * (f32(30.0) + f32(0.0))
+    assert c.position[0] == f32(1.0) - f32(np.sin(rad)) * dist and c.position[2] == f32(3.0) - f32(np.cos(rad)) * dist
+    assert c.position[1] == f32(2.0) + dist
+    before = list(c.position)
+    cam.Control(api.Camera.KEY_A | api.Camera.KEY_D | api.Camera.KEY_W | api.Camera.KEY_S | api.Camera.KEY_SPACE | api.Camera.KEY_LEFT_SHIFT,
+                frame_seconds=0.5)
+    assert np.allclose(list(c.position), before, atol=1e-6)               # opposite keys cancel
+    cam.Control(0, mouse_dx=100.0, mouse_dy=-400.0)
+    assert c.yaw == f32(30.0 - 50.0 + 360.0) and c.pitch == f32(90.0)    # wrapped into [0, 360), clamped
+    cam.Control(0, mouse_dx=-2000.0, mouse_dy=1000.0)
+    assert 0.0 <= c.yaw < 360.0 and c.pitch == f32(-90.0)
+    ip, iv = cam.matrices()
+    assert np.isfinite(ip).all() and np.isfinite(iv).all()
+
+
 @pytest.mark.parametrize("pattern", range(6))
 def test_parallel_sort_returns_the_permutation_of_std_sort(pattern):
     """exact_sort.hpp restates the library's introsort so that it can run on several threads; ties make the permutation
