@@ -40,6 +40,16 @@ __device__ __forceinline__ F3 reflect3(F3 i, F3 n) { float k = 2.0f * dot3(n, i)
 __device__ __forceinline__ float gl_min(float x, float y) { return y < x ? y : x; }
 __device__ __forceinline__ float gl_max(float x, float y) { return x < y ? y : x; }
 
+// One Horner step p * x + c of the fp64 series with the coefficient in a scalar register pair: written in C the compiler
+// materialises every coefficient with two v_mov_b32 and uses the two-address v_fmac_f64 — ~90 VALU slots per path in the
+// VALU-bound k_shade for nothing.  v_fma_f64 is the IEEE fused multiply-add either way, so results do not change.
+__device__ __forceinline__ double horner(double p, double x, double c)
+{
+	double r;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "s"(c));
+	return r;
+}
+
 __device__ inline void canon_sincos(float xf, float *s_out, float *c_out)
 {
 	const double TWO_OVER_PI = 0.63661977236758134308;
@@ -51,25 +61,25 @@ __device__ inline void canon_sincos(float xf, float *s_out, float *c_out)
 	y = fma(-kd, PIO2_LO, y);
 	double y2 = y * y;
 	double ps = -1.0 / 121645100408832000.0;
-	ps = fma(ps, y2, 1.0 / 355687428096000.0);
-	ps = fma(ps, y2, -1.0 / 1307674368000.0);
-	ps = fma(ps, y2, 1.0 / 6227020800.0);
-	ps = fma(ps, y2, -1.0 / 39916800.0);
-	ps = fma(ps, y2, 1.0 / 362880.0);
-	ps = fma(ps, y2, -1.0 / 5040.0);
-	ps = fma(ps, y2, 1.0 / 120.0);
-	ps = fma(ps, y2, -1.0 / 6.0);
+	ps = horner(ps, y2, 1.0 / 355687428096000.0);
+	ps = horner(ps, y2, -1.0 / 1307674368000.0);
+	ps = horner(ps, y2, 1.0 / 6227020800.0);
+	ps = horner(ps, y2, -1.0 / 39916800.0);
+	ps = horner(ps, y2, 1.0 / 362880.0);
+	ps = horner(ps, y2, -1.0 / 5040.0);
+	ps = horner(ps, y2, 1.0 / 120.0);
+	ps = horner(ps, y2, -1.0 / 6.0);
 	double sn = fma(y * y2, ps, y);
 	double pc = 1.0 / 2432902008176640000.0;
-	pc = fma(pc, y2, -1.0 / 6402373705728000.0);
-	pc = fma(pc, y2, 1.0 / 20922789888000.0);
-	pc = fma(pc, y2, -1.0 / 87178291200.0);
-	pc = fma(pc, y2, 1.0 / 479001600.0);
-	pc = fma(pc, y2, -1.0 / 3628800.0);
-	pc = fma(pc, y2, 1.0 / 40320.0);
-	pc = fma(pc, y2, -1.0 / 720.0);
-	pc = fma(pc, y2, 1.0 / 24.0);
-	pc = fma(pc, y2, -0.5);
+	pc = horner(pc, y2, -1.0 / 6402373705728000.0);
+	pc = horner(pc, y2, 1.0 / 20922789888000.0);
+	pc = horner(pc, y2, -1.0 / 87178291200.0);
+	pc = horner(pc, y2, 1.0 / 479001600.0);
+	pc = horner(pc, y2, -1.0 / 3628800.0);
+	pc = horner(pc, y2, 1.0 / 40320.0);
+	pc = horner(pc, y2, -1.0 / 720.0);
+	pc = horner(pc, y2, 1.0 / 24.0);
+	pc = horner(pc, y2, -0.5);
 	double cs = fma(y2, pc, 1.0);
 	long long k = (long long)kd;
 	double s, c;
@@ -116,16 +126,16 @@ __device__ inline float canon_pow(float xf, float yf)
 	double s = (m - 1.0) / (m + 1.0);
 	double s2 = s * s;
 	double p = 1.0 / 23.0;
-	p = fma(p, s2, 1.0 / 21.0);
-	p = fma(p, s2, 1.0 / 19.0);
-	p = fma(p, s2, 1.0 / 17.0);
-	p = fma(p, s2, 1.0 / 15.0);
-	p = fma(p, s2, 1.0 / 13.0);
-	p = fma(p, s2, 1.0 / 11.0);
-	p = fma(p, s2, 1.0 / 9.0);
-	p = fma(p, s2, 1.0 / 7.0);
-	p = fma(p, s2, 1.0 / 5.0);
-	p = fma(p, s2, 1.0 / 3.0);
+	p = horner(p, s2, 1.0 / 21.0);
+	p = horner(p, s2, 1.0 / 19.0);
+	p = horner(p, s2, 1.0 / 17.0);
+	p = horner(p, s2, 1.0 / 15.0);
+	p = horner(p, s2, 1.0 / 13.0);
+	p = horner(p, s2, 1.0 / 11.0);
+	p = horner(p, s2, 1.0 / 9.0);
+	p = horner(p, s2, 1.0 / 7.0);
+	p = horner(p, s2, 1.0 / 5.0);
+	p = horner(p, s2, 1.0 / 3.0);
 	double ln_m = 2.0 * fma(s * s2, p, s);
 	const double LOG2E = 1.44269504088896338700;
 	double log2x = fma(ln_m, LOG2E, (double)e);
@@ -137,19 +147,19 @@ __device__ inline float canon_pow(float xf, float yf)
 	const double LN2 = 0.69314718055994528623;
 	double z = f * LN2;
 	double q = 1.0 / 6227020800.0;
-	q = fma(q, z, 1.0 / 479001600.0);
-	q = fma(q, z, 1.0 / 39916800.0);
-	q = fma(q, z, 1.0 / 3628800.0);
-	q = fma(q, z, 1.0 / 362880.0);
-	q = fma(q, z, 1.0 / 40320.0);
-	q = fma(q, z, 1.0 / 5040.0);
-	q = fma(q, z, 1.0 / 720.0);
-	q = fma(q, z, 1.0 / 120.0);
-	q = fma(q, z, 1.0 / 24.0);
-	q = fma(q, z, 1.0 / 6.0);
-	q = fma(q, z, 0.5);
-	q = fma(q, z, 1.0);
-	q = fma(q, z, 1.0);
+	q = horner(q, z, 1.0 / 479001600.0);
+	q = horner(q, z, 1.0 / 39916800.0);
+	q = horner(q, z, 1.0 / 3628800.0);
+	q = horner(q, z, 1.0 / 362880.0);
+	q = horner(q, z, 1.0 / 40320.0);
+	q = horner(q, z, 1.0 / 5040.0);
+	q = horner(q, z, 1.0 / 720.0);
+	q = horner(q, z, 1.0 / 120.0);
+	q = horner(q, z, 1.0 / 24.0);
+	q = horner(q, z, 1.0 / 6.0);
+	q = horner(q, z, 0.5);
+	q = horner(q, z, 1.0);
+	q = horner(q, z, 1.0);
 	unsigned long long sb = (unsigned long long)((long long)n + 1023) << 52;
 	double scale = __longlong_as_double((long long)sb);
 	return (float)(q * scale);
