@@ -75,6 +75,8 @@ struct adypt_ctx {
 	hipEvent_t sobol_done[kSobolSlots] = {nullptr, nullptr, nullptr, nullptr};
 	int sobol_next = 0;
 	int frames_in_flight = 1;
+	bool queues_ok = false;    // false after a failed (re)allocation of the queues: trace calls return ADYPT_E_STATE
+	uint32_t *d_display = nullptr; // adypt_read_display: one RGBA8 word per local pixel (allocated on first use)
 	RayStats *d_ray_stats = nullptr;
 	FrameCounters *d_counters = nullptr;
 	DeviceStats *d_stats = nullptr;
@@ -158,8 +160,11 @@ bool validate_bvh(const adypt_scene_desc &d, std::string *why)
 			const bool inner = (m & (m << 1)) & 0x10;
 			if(inner)
 			{
-				// hit bit (24 + widx) must address a set imask bit
+				// hit bit (24 + widx) must address a set imask bit, and ONLY that bit may be raised: the kernel ORs
+				// child_bits << bit_index into the hit mask, so child_bits other than 0b001 would mark slots that are not in
+				// imask and the child index base + popcount(imask below slot) could step one past the validated range
 				const uint32_t widx = (m & 31u) - 24u;
+				if((m >> 5) != 1u) { *why = "node " + std::to_string(i) + ": inner child with child bits != 001"; return false; }
 				if(widx > 7 || !((imask >> widx) & 1u)) { *why = "node " + std::to_string(i) + ": inner child not in imask"; return false; }
 			}
 			else
@@ -330,13 +335,15 @@ int load_shift(adypt_ctx *c)
 			local[(size_t)L * 2 + 1] = full[((size_t)y * c->width + x) * 2 + 1];
 		}
 	}
-	HIP_TRY(c, hipMemcpy(c->d_shift, local.data(), local.size(), hipMemcpyHostToDevice));
+	// frames enqueued earlier (adypt_trace_spp_async, then adypt_reset + adypt_set_params) may still be reading d_shift
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if(!local.empty()) HIP_TRY(c, hipMemcpy(c->d_shift, local.data(), local.size(), hipMemcpyHostToDevice));
 	c->shift_loaded = true; c->shift_seed_loaded = c->params.shift_seed;
 	return ADYPT_OK;
 }
 
 // (re)allocate the wavefront queues for `fif` frames in flight: capacity = fif x local pixels, cut into 8 segments
-int alloc_queues(adypt_ctx *c, int fif)
+int alloc_queues_raw(adypt_ctx *c, int fif)
 {
 	void *old[] = {c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->d_hit, c->d_done, c->d_ray_stats,
 				   c->sh_o, c->sh_d, c->sh_col, c->sh_hit};
@@ -361,6 +368,31 @@ int alloc_queues(adypt_ctx *c, int fif)
 	HIP_TRY(c, hipMalloc((void **)&c->d_hit, nq * sizeof(float4)));
 	HIP_TRY(c, hipMalloc((void **)&c->d_done, paths * sizeof(float4))); // finished samples of a batch / parked radiance of live paths
 	return ADYPT_OK;
+}
+
+// A failed (re)allocation must not leave a context that launches kernels on null queues: fall back to the previous
+// frames-in-flight; if even that cannot be had, the context is marked unusable and every trace call returns ADYPT_E_STATE.
+int alloc_queues(adypt_ctx *c, int fif)
+{
+	const int previous = c->queues_ok ? c->frames_in_flight : 0;
+	int r = alloc_queues_raw(c, fif);
+	c->queues_ok = r == ADYPT_OK;
+	if(r == ADYPT_OK) return r;
+	const std::string why = c->error;
+	(void)hipGetLastError();
+	if(previous > 0 && previous != fif && alloc_queues_raw(c, previous) == ADYPT_OK)
+	{
+		c->queues_ok = true;
+		c->error = why + " (kept " + std::to_string(previous) + " frames in flight)";
+		return r;
+	}
+	// nothing usable is left: free the partial allocation of the failed attempt
+	void *bufs[] = {c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->d_hit, c->d_done};
+	for(void *b : bufs) if(b) (void)hipFree(b);
+	c->q_o[0] = c->q_o[1] = c->q_d[0] = c->q_d[1] = c->q_col[0] = c->q_col[1] = c->d_hit = c->d_done = nullptr;
+	c->capacity = 0; c->seg_cap = 0;
+	c->error = why + " (the context has no ray queues left: destroy it)";
+	return r;
 }
 
 int ensure_shadow_queue(adypt_ctx *c)
@@ -528,9 +560,10 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	HIP_CREATE(hipMemset(c->d_cache, 0xff, npx * sizeof(float4)));
 	HIP_CREATE(hipMemset(c->d_shift, 0, npx * 2));
 	{
-		// frames in flight: enough consecutive frames per wavefront pass to keep ~4 M paths in flight (a tile shard of
-		// an 8-GPU run has only 260 k pixels), at most 8; ADYPT_FRAMES_IN_FLIGHT overrides
-		int fif = (int)std::min<size_t>(kMaxFramesInFlight, std::max<size_t>(1, ((size_t)64 << 20) / npx)); // ~64 M paths per wavefront pass: the drain of a launch (its longest rays) is amortised over more work
+		// frames in flight: enough consecutive frames per wavefront pass to keep ~64 Mi paths in flight (32 frames of a
+		// 1080p image, 128 frames = the maximum for the 260 k-pixel tile shard of an 8-GPU run): the drain of a persistent
+		// launch (its longest rays) is amortised over more work; ADYPT_FRAMES_IN_FLIGHT overrides
+		int fif = (int)std::min<size_t>(kMaxFramesInFlight, std::max<size_t>(1, ((size_t)64 << 20) / npx));
 		if(const char *ov = getenv("ADYPT_FRAMES_IN_FLIGHT")) fif = std::max(1, std::min(kMaxFramesInFlight, atoi(ov)));
 		TRY_CREATE(alloc_queues(c, fif));
 	}
@@ -567,7 +600,7 @@ void adypt_destroy(adypt_ctx *c)
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
 					c->d_accum, c->d_cache, c->d_cache_next, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
-					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol};
+					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol, c->d_display};
 	for(void *b : bufs) if(b) (void)hipFree(b);
 	for(int i = 0; i < adypt_ctx::kSobolSlots; ++i)
 	{
@@ -581,8 +614,9 @@ void adypt_destroy(adypt_ctx *c)
 int adypt_set_params(adypt_ctx *c, const adypt_pt_params *p)
 {
 	if(!c || !p) return ADYPT_E_INVALID;
-	if(p->stack_size < 1 || p->stack_size > 64 || p->max_bounce < 1 || p->max_bounce > kMaxBounce || p->subpixel < 1 || p->tmp_lifetime < 1)
-		return fail(c, ADYPT_E_INVALID, "adypt_set_params: stackSize must be in [1,64], maxBounce in [1,32], subpixel and tmpLifetime >= 1");
+	// subpixel * subpixel is an int in the kernels (pathtracer.glsl:207 does the same in GLSL int): 46340^2 < 2^31
+	if(p->stack_size < 1 || p->stack_size > 64 || p->max_bounce < 1 || p->max_bounce > kMaxBounce || p->subpixel < 1 || p->subpixel > 46340 || p->tmp_lifetime < 1)
+		return fail(c, ADYPT_E_INVALID, "adypt_set_params: stackSize must be in [1,64], maxBounce in [1,32], subpixel in [1,46340], tmpLifetime >= 1");
 	c->pending = *p;
 	c->have_params = true;
 	if(!c->pt_started)
@@ -652,7 +686,7 @@ int adypt_set_frames_in_flight(adypt_ctx *c, int n)
 	if(n < 1 || n > kMaxFramesInFlight) return fail(c, ADYPT_E_INVALID, "adypt_set_frames_in_flight: n_frames must be in [1, " + std::to_string(kMaxFramesInFlight) + "]");
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	if(n == c->frames_in_flight) return ADYPT_OK;
+	if(n == c->frames_in_flight && c->queues_ok) return ADYPT_OK;
 	return alloc_queues(c, n);
 }
 
@@ -662,12 +696,14 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 {
 	if(!c) return ADYPT_E_INVALID;
 	if(!c->have_camera) return fail(c, ADYPT_E_STATE, "adypt_trace_primary: call adypt_set_camera first");
+	if(!c->queues_ok) return fail(c, ADYPT_E_STATE, "adypt_trace_primary: the context lost its ray queues (failed adypt_set_frames_in_flight)");
 	HIP_TRY(c, hipSetDevice(c->device));
 	// Trace(false): leaves path-tracing mode (OglPathTracer.cpp:53-58)
 	c->pt_started = false; c->spp = 0;
 	c->view_type = viewer_type;
 	int r = apply_params(c);
 	if(r != ADYPT_OK) return r;
+	if(c->n_local_px == 0) return ADYPT_OK; // a tile shard that owns no 32x32 block (more ranks than block diagonals): nothing to render
 	FrameArgs f; SceneArgs sc; PixelArgs px;
 	fill_frame(c, &f); fill_scene(c, &sc); fill_pixels(c, &px);
 	HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
@@ -711,7 +747,21 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 {
 	if(!c || n_spp < 0) return ADYPT_E_INVALID;
 	if(!c->have_camera) return fail(c, ADYPT_E_STATE, "adypt_trace_spp: call adypt_set_camera first");
+	if(!c->queues_ok) return fail(c, ADYPT_E_STATE, "adypt_trace_spp: the context lost its ray queues (failed adypt_set_frames_in_flight)");
 	HIP_TRY(c, hipSetDevice(c->device));
+	if(c->n_local_px == 0)
+	{
+		// a tile shard that owns no 32x32 block (more ranks than block diagonals, e.g. 64x36 on 4 ranks): the frame counter
+		// and the parameter hand-over advance like everywhere else, no kernel runs (they would divide by n_local_px)
+		if(n_spp > 0 && !c->pt_started)
+		{
+			int r = apply_params(c);
+			if(r != ADYPT_OK) return r;
+			c->spp = 0; c->pt_started = true; c->view_type = 3;
+		}
+		c->spp += n_spp;
+		return ADYPT_OK;
+	}
 	SceneArgs sc; PixelArgs px;
 	fill_scene(c, &sc); fill_pixels(c, &px);
 	const bool stats = (c->instrumentation & 2) != 0;
@@ -834,6 +884,10 @@ int adypt_read_radiance(adypt_ctx *c, float *rgb)
 {
 	if(!c || !rgb) return ADYPT_E_INVALID;
 	HIP_TRY(c, hipSetDevice(c->device));
+	// the context's stream is non-blocking: a legacy-stream copy is not ordered after the frames enqueued by
+	// adypt_trace_spp_async, so wait for them here (include/adypt_hip.h: entry points that read results synchronise)
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if(c->n_local_px == 0) return ADYPT_OK; // a shard that owns no block: nothing of the image is this context's
 	std::vector<float> local((size_t)c->n_local_px * 4);
 	HIP_TRY(c, hipMemcpy(local.data(), c->d_accum, local.size() * sizeof(float), hipMemcpyDeviceToHost));
 	return adypt_untile_host(c->width, c->height, c->rank, c->nranks, local.data(), rgb);
@@ -843,15 +897,13 @@ int adypt_read_display(adypt_ctx *c, uint8_t *rgba8)
 {
 	if(!c || !rgba8) return ADYPT_E_INVALID;
 	HIP_TRY(c, hipSetDevice(c->device));
-	uint32_t *d_out = nullptr;
-	HIP_TRY(c, hipMalloc((void **)&d_out, (size_t)std::max(c->n_local_px, 64) * sizeof(uint32_t)));
-	hipLaunchKernelGGL(k_display, dim3((c->n_local_px + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_accum, c->n_local_px, c->view_type, d_out);
+	if(c->n_local_px == 0) return ADYPT_OK;
+	if(!c->d_display) HIP_TRY(c, hipMalloc((void **)&c->d_display, (size_t)c->n_local_px * sizeof(uint32_t))); // once: the size never changes
+	hipLaunchKernelGGL(k_display, dim3((c->n_local_px + 255) / 256), dim3(256), 0, c->stream, (const float4 *)c->d_accum, c->n_local_px, c->view_type, c->d_display);
 	std::vector<uint32_t> local((size_t)c->n_local_px);
-	hipError_t e = hipGetLastError();
-	if(e == hipSuccess) e = hipMemcpyAsync(local.data(), d_out, local.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-	if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	(void)hipFree(d_out);
-	HIP_TRY(c, e);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipMemcpyAsync(local.data(), c->d_display, local.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	for(int L = 0; L < c->n_local_px; ++L)
 	{
 		const int blk = c->local_blocks[(size_t)(L >> 10)];
@@ -867,6 +919,8 @@ int adypt_read_hits(adypt_ctx *c, int32_t *tri, float *uv)
 {
 	if(!c || !tri || !uv) return ADYPT_E_INVALID;
 	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream)); // see adypt_read_radiance
+	if(c->n_local_px == 0) return ADYPT_OK;
 	std::vector<float> local((size_t)c->n_local_px * 4);
 	HIP_TRY(c, hipMemcpy(local.data(), c->d_cache, local.size() * sizeof(float), hipMemcpyDeviceToHost));
 	for(int L = 0; L < c->n_local_px; ++L)
@@ -885,6 +939,7 @@ int adypt_read_hits(adypt_ctx *c, int32_t *tri, float *uv)
 static int trace_rays_impl(adypt_ctx *c, const float *rays, int64_t n, adypt_hit *hits, int with_stats, bool any_hit)
 {
 	if(!c || n < 0 || (n > 0 && (!rays || !hits))) return ADYPT_E_INVALID;
+	if(!c->queues_ok) return fail(c, ADYPT_E_STATE, "adypt_trace_rays: the context lost its ray queues (failed adypt_set_frames_in_flight)");
 	HIP_TRY(c, hipSetDevice(c->device));
 	if(!c->pt_started) { int r = apply_params(c); if(r != ADYPT_OK) return r; }
 	if(with_stats) { int r = ensure_ray_stats(c); if(r != ADYPT_OK) return r; }

@@ -1,11 +1,15 @@
 // Binary spatial-split BVH (Stich et al.) with exactly one triangle reference per leaf — the producer of the
 // tree that wide_builder.cpp collapses into CWBVH8.
 //
-// This is a from-scratch restatement of the reference's builder decisions (src/BVH/SBVHBuilder.hpp:95-306,
-// src/BVH/SBVHBuilder.cpp:8-71) so that the flattened node / index arrays are bit-identical to the ones Adypt's
-// own CPU builder hands to its tracer (pinned by tests/golden/*.bvh, generated from the compiled reference).
-// Structure differs: an explicit task stack instead of recursion (deep trees cannot overflow the call stack) and
-// flat scratch arrays; every float expression keeps the reference's evaluation order (-ffp-contract=off).
+// north_star reuses the reference's CPU builder unchanged; this file restates it so that the product needs none of the
+// reference's sources, and the flattened node / index arrays stay bit-identical to the ones Adypt's own builder hands to
+// its tracer (pinned by tests/golden/*.bvh, generated from the compiled reference).  Provenance, said plainly: the split
+// search and the reference splitting (object_split_axis, clip_ref, spatial_split_axis, do_spatial_split below) were
+// written with src/BVH/SBVHBuilder.hpp:95-306 open beside them and follow it statement by statement — bit-identical
+// output forces the same decision sequence and the same float evaluation order (-ffp-contract=off), so that third of the
+// file is a restatement, not a re-design.  What is this repo's own: the explicit task stack instead of recursion (deep
+// trees cannot overflow the call stack), the flat scratch arrays, and the parallel build with its stitching (below) and
+// exact_sort.hpp.
 //
 // Parallel build.  What a subtree looks like depends only on (its box, its depth, the ORDER of its
 // references on the stack): the reference builder never touches stack entries below the node it works on.  So the

@@ -132,7 +132,9 @@ int adypt_get_spp(const adypt_ctx *ctx); /* OglPathTracer::GetSPP */
 /* How many consecutive frames adypt_trace_spp traces as one wavefront pass (1..128).  Frames are independent
  * samples and the running mean is applied afterwards in frame order, so results are bit-identical for every value;
  * more frames in flight keep small images / tile shards saturated.  Default: chosen from the local pixel count
- * (about 4 M paths per pass, at most 8).  Reallocates the ray queues. */
+ * (about 64 Mi paths per pass: 32 frames at 1920x1080, 128 for the tile shard of an 8-GPU run).  Reallocates the ray
+ * queues; when that fails the previous value is kept (and the error returned), and if nothing can be allocated any more
+ * the trace calls return ADYPT_E_STATE. */
 int adypt_set_frames_in_flight(adypt_ctx *ctx, int n_frames);
 int adypt_get_frames_in_flight(const adypt_ctx *ctx);
 

@@ -24,9 +24,22 @@ def _decode(exr, out):
     return np.fromfile(out, dtype=np.float32).reshape(h, w, 4)
 
 
-@pytest.mark.skipif(not (os.path.exists(DROPIN) and os.path.exists(REFBIN)), reason="oracle/_ref binaries not built (no reference sources)")
+def _require_ref_binaries():
+    """oracle/_ref/ is git-ignored but travels to the GPU box with the snapshot.  Where the reference sources exist the
+    binaries can always be built (oracle/Makefile), so their absence is a failure there; elsewhere it is a visible skip."""
+    if os.path.exists(DROPIN) and os.path.exists(REFBIN):
+        return
+    if os.path.isdir("/root/reference"):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert os.path.exists(DROPIN) and os.path.exists(REFBIN), "oracle/_ref binaries missing although /root/reference exists: run `make -C oracle`"
+        return
+    pytest.skip("DROP-IN TEST NOT RUN: oracle/_ref/{adypt_dropin,adypt_ref} are absent and there are no reference sources here to build "
+                "them from (they are built in the build container by __graft_entry__.build() and shipped with the gpurun snapshot)")
+
+
 @pytest.mark.parametrize("name,w,h,spp", [("tiny0", 96, 64, 5), ("sibenik", 160, 90, 3)])
 def test_reference_cpu_half_plus_this_library_equals_the_product_pipeline(name, w, h, spp, tmp_path):
+    _require_ref_binaries()
     from adypt_amd import scenes
     spec = scenes.make_scene(name, str(tmp_path), width=w, height=h, pt={"maxBounce": 5, "stackSize": 24, "tmpLifetime": 2})
     ref_exr, our_exr = str(tmp_path / "dropin.exr"), str(tmp_path / "ours.exr")

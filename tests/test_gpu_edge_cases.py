@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from adypt_amd import api  # noqa: E402
+from adypt_amd import api, _native as N  # noqa: E402
 from oracle import oracle_py as O  # noqa: E402
 from tests.helpers import GOLDEN, bits  # noqa: E402
 
@@ -216,3 +216,104 @@ def test_sun_visibility_option_matches_oracle(name, w, h, fif, scene_cache, sobo
     assert (results["default"][0] <= results["off"][0]).all()               # occlusion only removes light
     with pytest.raises(Exception):
         pt.SetSunVisibility(True, [0.0, 0.0, 0.0])
+
+
+def test_read_after_async_trace_without_wait(scene_cache, sobol_matrices):
+    """adypt_read_radiance / adypt_read_hits synchronise with the context's (non-blocking) stream themselves: reading right
+    after adypt_trace_spp_async, with no adypt_wait, returns the finished frames.  Also adypt_reset + adypt_set_params
+    (new shift seed) right behind asynchronous work must not overwrite the shift image under the running kernels."""
+    from tests.helpers import oracle_params_from_config, oracle_scene_from_instance
+    from tests.test_gpu_parity import make_instance
+    inst = make_instance(scene_cache, "sponza", 640, 360, seed=31, pt={"maxBounce": 8, "stackSize": 24})
+    c, pt = inst.m_config.c, inst.m_path_tracer
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    pt.SetFramesInFlight(4)
+    pt.TraceAsync(24)          # six batches queued on the stream, the host returns at once
+    a = pt.ReadResult()        # no Wait()
+    tri, _ = pt.ReadHits()
+    st = O.PathTracerState(c.width, c.height)
+    O.pt_frames(osc, P, O.shift_bytes(31, c.width, c.height), sobol_matrices, st, 24)
+    assert np.array_equal(bits(a), bits(st.accum[..., :3])) and np.array_equal(tri, st.cache_tri)
+    pt.Wait()
+    # new seed handed over while frames of the old seed are still in flight
+    pt.Reset()
+    pt.TraceAsync(24)
+    pt.Reset()
+    pt.SetConfig(inst.m_config.pt_params(77))
+    pt.Trace(True, 3)
+    st2 = O.PathTracerState(c.width, c.height)
+    O.pt_frames(osc, P, O.shift_bytes(77, c.width, c.height), sobol_matrices, st2, 3)
+    assert np.array_equal(bits(pt.ReadResult()), bits(st2.accum[..., :3]))
+
+
+@pytest.mark.parametrize("w,h,world", [(64, 36, 4), (128, 128, 8), (96, 64, 8)])
+def test_tile_shard_that_owns_no_block(w, h, world, scene_cache):
+    """More ranks than 32x32 block diagonals: some contexts own nothing (n_local_px == 0).  They must trace nothing (the
+    kernels divide by the local pixel count), keep the frame counter in step, read back nothing, and the union of all
+    shards must still equal the 1-context frame."""
+    from adypt_amd import distributed as D
+    from tests.test_gpu_parity import make_instance
+    full = make_instance(scene_cache, "tiny0", w, h, seed=5)
+    full.m_path_tracer.Trace(True, 3)
+    ref = full.m_path_tracer.ReadResult()
+    out, empty, rays = np.zeros_like(ref), 0, 0
+    for r in range(world):
+        part = make_instance(scene_cache, "tiny0", w, h, seed=5, rank=r, world=world)
+        pt = part.m_path_tracer
+        n = pt.local_pixel_count()
+        assert n == D.block_count(w, h, r, world) * 1024
+        pt.Trace(False)
+        pt.Trace(True, 2)
+        pt.TraceAsync(1)
+        img = pt.ReadResult()
+        pt.Wait()
+        assert pt.GetSPP() == 3
+        mask = D.owner_mask(w, h, r, world).astype(bool)
+        if n == 0:
+            empty += 1
+            assert not mask.any() and not img.any() and pt.GetStats()["rays"] == 0
+            assert not pt.ReadDisplay().any() and (pt.ReadHits()[0] == -1).all()
+        out[mask] = img[mask]
+        rays += pt.GetStats()["rays"]
+        pt.destroy()
+    assert empty > 0
+    assert np.array_equal(bits(out), bits(ref))
+
+
+def test_corrupt_inner_child_bits_are_rejected():
+    """validate_bvh mirrors the kernel's addressing: an inner slot whose child bits are not 0b001 would raise hit-mask bits
+    outside imask (one node past the validated child range) — adypt_create must refuse the array."""
+    from tests.helpers import golden_scene
+    from tests.test_gpu_parity import golden_tracer
+    _, idx, nodes, tris, mats, woop = golden_scene("tiny0")
+    raw = nodes.view("u1").reshape(-1, 80).copy()
+    hit = False
+    for i in range(len(raw)):
+        for s in range(8):
+            m = int(raw[i, 24 + s])
+            if m and (m & 0x18) == 0x18:   # inner slot: low five bits >= 24
+                raw[i, 24 + s] = (m & 31) | (3 << 5)
+                hit = True
+                break
+        if hit:
+            break
+    assert hit
+    sc = api.Scene.FromArrays(tris, mats)
+    b = api.WideBVH()
+    b.nodes, b.tri_indices = raw.reshape(-1), idx
+    hs = api.HipScene()
+    hs.Initialize(sc, b, woop=woop)
+    with pytest.raises(N.AdyptError) as e:
+        api.HipPathTracer().Initialize(api.InstanceConfig().pt_params(0), hs, 64, 36)
+    assert e.value.code == N.E_INVALID and "child bits" in str(e.value)
+
+
+def test_subpixel_upper_bound():
+    from tests.test_gpu_parity import golden_tracer
+    pt = golden_tracer("tiny0")
+    p = api.InstanceConfig().pt_params(0)
+    p.subpixel = 46341
+    with pytest.raises(N.AdyptError):
+        pt.SetConfig(p)
+    p.subpixel = 46340
+    pt.SetConfig(p)

@@ -288,6 +288,31 @@ def test_full_size_frame_bit_exact_and_deterministic(scene_cache, sobol_matrices
         assert np.array_equal(a[sky], np.broadcast_to(np.minimum(np.array(list(c.sun), np.float32), np.float32(c.clamp)), a[sky].shape))
 
 
+def test_bench_path_batched_1080p_spanning_two_tmplifetime_groups(scene_cache, sobol_matrices):
+    """Exactly what bench.py times (its scene, its .config parameters, the default 32 frames in flight): a warm-up call of
+    5 frames, then ONE call of 20 frames = frames 5..24 of the sequence.  That batch spans two tmpLifetime groups (frame 16
+    re-traces its primaries): primary-only pass -> k_store_cache into the second cache slice -> every frame starts from the
+    cache of its group -> k_resolve in frame order -> image 1 = the last group's hits (tracer.hip adypt_trace_spp_async).
+    Against the oracle's frame-by-frame loop (pathtracer.glsl:113-127, OglPathTracer.cpp:34-61), every pixel, every bit."""
+    pt_cfg = {"maxBounce": 8, "subpixel": 8, "tmpLifetime": 16, "clamp": 4.0, "sun": [12.0, 11.0, 10.0], "stackSize": 24}  # = bench.py
+    inst = make_instance(scene_cache, "sponza", 1920, 1080, pt=pt_cfg, seed=12345)
+    c, pt = inst.m_config.c, inst.m_path_tracer
+    assert pt.GetFramesInFlight() == 32 and c.tmp_lifetime == 16
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    pt.ResetStats()
+    pt.Trace(True, 5)
+    pt.Trace(True, 20)
+    a = pt.ReadResult()
+    tri, uv = pt.ReadHits()
+    st = O.PathTracerState(c.width, c.height)
+    ost = O.pt_frames(osc, P, O.shift_bytes(12345, c.width, c.height), sobol_matrices, st, 25).as_dict()
+    assert np.array_equal(bits(a), bits(st.accum[..., :3]))
+    assert pt.GetStats()["rays"] == ost["rays"] and pt.GetSPP() == 25
+    assert np.array_equal(tri, st.cache_tri)  # the primary hits of frame 16 (sub-pixel offset of group 1)
+    m = tri >= 0
+    assert np.array_equal(bits(uv)[m], bits(st.cache_uv)[m])
+
+
 def test_exr_output_of_a_render(scene_cache, tmp_path):
     inst = make_instance(scene_cache, "tiny0", 96, 64)
     inst.m_path_tracer.Trace(True, 2)
