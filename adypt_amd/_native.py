@@ -88,6 +88,8 @@ _SIGS = {
     "adypt_get_spp": (C.c_int, [C.c_void_p]),
     "adypt_set_frames_in_flight": (C.c_int, [C.c_void_p, C.c_int]),
     "adypt_get_frames_in_flight": (C.c_int, [C.c_void_p]),
+    "adypt_set_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
+    "adypt_get_lookahead_frames": (C.c_int, [C.c_void_p]),
     "adypt_read_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adypt_read_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "adypt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
@@ -106,6 +108,29 @@ _SIGS = {
     "adypt_assemble_radiance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "adypt_shard_block_count": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "adypt_untile_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    # native multi-GPU (RCCL inside the library)
+    "adypt_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int]),
+    "adypt_destroy_multi": (None, [C.c_void_p]),
+    "adypt_multi_last_error": (C.c_char_p, [C.c_void_p]),
+    "adypt_multi_device_count": (C.c_int, [C.c_void_p]),
+    "adypt_multi_context": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "adypt_multi_set_params": (C.c_int, [C.c_void_p, C.POINTER(PtParams)]),
+    "adypt_multi_set_camera": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "adypt_multi_set_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
+    "adypt_multi_trace_primary": (C.c_int, [C.c_void_p, C.c_int]),
+    "adypt_multi_trace_spp": (C.c_int, [C.c_void_p, C.c_int]),
+    "adypt_multi_reset": (C.c_int, [C.c_void_p]),
+    "adypt_multi_get_spp": (C.c_int, [C.c_void_p]),
+    "adypt_multi_read_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "adypt_multi_gather_radiance": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "adypt_multi_comm_init": (C.c_int, [C.c_void_p]),
+    "adypt_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "adypt_comm_init": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "adypt_comm_gather_radiance": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "adypt_comm_read_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "adypt_comm_allreduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
+    "adypt_comm_barrier": (C.c_int, [C.c_void_p]),
+    "adypt_device_synchronize": (C.c_int, [C.c_void_p]),
     # adypt_host.h
     "adypt_config_default": (None, [C.POINTER(Config)]),
     "adypt_config_load": (C.c_int, [C.c_char_p, C.POINTER(Config)]),
@@ -166,7 +191,11 @@ def _share_torch_hip_runtime() -> None:
         try:
             C.CDLL(rt, mode=C.RTLD_GLOBAL)
         except OSError:
-            pass
+            return
+        # the RCCL that goes with that runtime (the library dlopens RCCL on first use of the native multi-GPU path)
+        rccl = os.path.join(os.path.dirname(rt), "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("ADYPT_RCCL_LIB", rccl)
 
 
 _share_torch_hip_runtime()
@@ -175,7 +204,7 @@ for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export what the headers declare
     _fn.restype = _res
     _fn.argtypes = _args
-if lib.adypt_abi_version() != 1:
+if lib.adypt_abi_version() != 2:
     raise ImportError("adypt_amd: ABI version mismatch")
 
 

@@ -301,6 +301,7 @@ class HipPathTracer:
                    tile_rank: int = 0, tile_nranks: int = 1) -> None:
         self.destroy()
         self.width, self.height = width, height
+        self.tile_rank, self.tile_nranks = tile_rank, tile_nranks
         s, b = scene.scene, scene.bvh
         tex_arr = (N.Texture * max(1, len(s.textures)))()
         self._keep = [s.triangles, s.materials, b.nodes, b.tri_indices, scene.woop, tex_arr] + list(s.textures)
@@ -360,6 +361,13 @@ class HipPathTracer:
 
     def GetFramesInFlight(self) -> int:
         return N.lib.adypt_get_frames_in_flight(self._ctx)
+
+    def SetLookahead(self, enabled: bool) -> None:
+        """One Trace(true) per call (Instance::Update) at batched throughput: see adypt_set_lookahead."""
+        N.check(N.lib.adypt_set_lookahead(self._ctx, 1 if enabled else 0), self._ctx)
+
+    def GetLookaheadFrames(self) -> int:
+        return N.lib.adypt_get_lookahead_frames(self._ctx)
 
     def ReadResult(self) -> np.ndarray:
         rgb = np.zeros((self.height, self.width, 3), dtype=np.float32)
@@ -423,10 +431,136 @@ class HipPathTracer:
     def assemble_radiance(self, gathered_device_ptr: int, stride_float4: int, rgb_device_ptr: int) -> None:
         N.check(N.lib.adypt_assemble_radiance(self._ctx, gathered_device_ptr, stride_float4, rgb_device_ptr), self._ctx)
 
+    # ---- one process per GPU: the library's own RCCL communicator (adypt_comm_*) ----
+    def CommInit(self, unique_id: bytes) -> None:
+        assert len(unique_id) == 128
+        N.check(N.lib.adypt_comm_init(self._ctx, unique_id), self._ctx)
+
+    def CommGatherDevice(self) -> Optional[int]:
+        """Collective: the one gather.  Rank 0 gets the device pointer of the assembled W x H x 3 fp32 image, the others None."""
+        p = C.c_void_p()
+        N.check(N.lib.adypt_comm_gather_radiance(self._ctx, C.byref(p)), self._ctx)
+        return p.value
+
+    def CommReadResult(self) -> Optional[np.ndarray]:
+        """Collective: gather + device-to-host copy on rank 0 (None elsewhere)."""
+        rgb = np.zeros((self.height, self.width, 3), dtype=np.float32) if self.tile_rank == 0 else None
+        N.check(N.lib.adypt_comm_read_radiance(self._ctx, None if rgb is None else rgb.ctypes.data), self._ctx)
+        return rgb
+
+    def CommAllReduce(self, values, op: str = "sum"):
+        arr = (C.c_double * len(values))(*[float(v) for v in values])
+        N.check(N.lib.adypt_comm_allreduce(self._ctx, arr, len(values), {"sum": 0, "max": 1}[op]), self._ctx)
+        return [float(v) for v in arr]
+
+    def CommBarrier(self) -> None:
+        N.check(N.lib.adypt_comm_barrier(self._ctx), self._ctx)
+
+    def DeviceSynchronize(self) -> None:
+        N.check(N.lib.adypt_device_synchronize(self._ctx), self._ctx)
+
     def destroy(self) -> None:
         if self._ctx:
             N.lib.adypt_destroy(self._ctx)
             self._ctx = C.c_void_p()
+
+    def __del__(self) -> None:
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class MultiPathTracer:
+    """One host process driving N GPUs through the library's own multi-device boundary (adypt_create_multi): tile rank i on
+    devices[i], scene replicated, the radiance gathered on devices[0] with RCCL inside adypt_multi_read_radiance.  Same method
+    names as HipPathTracer / OglPathTracer."""
+
+    def __init__(self) -> None:
+        self._m = C.c_void_p()
+        self.m_viewer_type = ViewerTypes.kDiffuse
+
+    def _check(self, code: int) -> None:
+        if code != N.ADYPT_OK:
+            msg = N.lib.adypt_multi_last_error(self._m if self._m else None)
+            raise N.AdyptError(code, (msg or b"").decode("utf-8", "replace"))
+
+    def Initialize(self, config: N.PtParams, scene: HipScene, width: int, height: int, devices: Sequence[int] = (0,)) -> None:
+        self.destroy()
+        self.width, self.height = width, height
+        s, b = scene.scene, scene.bvh
+        tex_arr = (N.Texture * max(1, len(s.textures)))()
+        self._keep = [s.triangles, s.materials, b.nodes, b.tri_indices, scene.woop, tex_arr] + list(s.textures)
+        for i, t in enumerate(s.textures):
+            tex_arr[i].width, tex_arr[i].height, tex_arr[i].rgb = t.shape[1], t.shape[0], t.ctypes.data
+        d = N.SceneDesc()
+        d.nodes, d.n_nodes = b.nodes.ctypes.data, len(b.nodes) // NODE_BYTES
+        d.tri_indices, d.n_refs = b.tri_indices.ctypes.data, len(b.tri_indices)
+        d.woop = None if scene.woop is None else scene.woop.ctypes.data
+        d.triangles, d.n_tris = s.triangles.ctypes.data, len(s.triangles) // TRI_BYTES
+        d.materials, d.n_mats = (s.materials.ctypes.data if len(s.materials) else None), len(s.materials) // MAT_BYTES
+        d.textures, d.n_textures = (C.addressof(tex_arr) if s.textures else None), len(s.textures)
+        d.width, d.height, d.device, d.tile_rank, d.tile_nranks = width, height, 0, 0, 1
+        devs = (C.c_int * len(devices))(*devices)
+        self._check(N.lib.adypt_create_multi(C.byref(self._m), C.byref(d), devs, len(devices)))
+        self.SetConfig(config)
+
+    def SetConfig(self, config: N.PtParams) -> None:
+        self._check(N.lib.adypt_multi_set_params(self._m, C.byref(config)))
+
+    def SetCamera(self, inv_projection: np.ndarray, inv_view: np.ndarray, position) -> None:
+        ip = np.ascontiguousarray(inv_projection, dtype=np.float32).reshape(16)
+        iv = np.ascontiguousarray(inv_view, dtype=np.float32).reshape(16)
+        pos = np.ascontiguousarray(position, dtype=np.float32).reshape(3)
+        self._check(N.lib.adypt_multi_set_camera(self._m, pos.ctypes.data, ip.ctypes.data, iv.ctypes.data))
+
+    def SetLookahead(self, enabled: bool) -> None:
+        self._check(N.lib.adypt_multi_set_lookahead(self._m, 1 if enabled else 0))
+
+    def CommInit(self) -> None:
+        self._check(N.lib.adypt_multi_comm_init(self._m))
+
+    def Trace(self, enable_pt: bool, n_spp: int = 1) -> None:
+        if enable_pt:
+            self.m_viewer_type = ViewerTypes.kPTRadiance
+            self._check(N.lib.adypt_multi_trace_spp(self._m, n_spp))
+        else:
+            if self.m_viewer_type == ViewerTypes.kPTRadiance:
+                self.m_viewer_type = ViewerTypes.kDiffuse
+            self._check(N.lib.adypt_multi_trace_primary(self._m, self.m_viewer_type))
+
+    def Reset(self) -> None:
+        self._check(N.lib.adypt_multi_reset(self._m))
+
+    def GetSPP(self) -> int:
+        return N.lib.adypt_multi_get_spp(self._m)
+
+    def DeviceCount(self) -> int:
+        return N.lib.adypt_multi_device_count(self._m)
+
+    def ContextStats(self, i: int) -> dict:
+        st = N.Stats()
+        N.check(N.lib.adypt_get_stats(N.lib.adypt_multi_context(self._m, i), C.byref(st)))
+        return st.as_dict()
+
+    def ReadResult(self) -> np.ndarray:
+        rgb = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        self._check(N.lib.adypt_multi_read_radiance(self._m, rgb.ctypes.data))
+        return rgb
+
+    def GatherDevice(self) -> int:
+        """Device pointer (on devices[0]) of the assembled W x H x 3 fp32 image; owned by the library."""
+        p = C.c_void_p()
+        self._check(N.lib.adypt_multi_gather_radiance(self._m, C.byref(p)))
+        return p.value
+
+    def SaveResult(self, filename: str, save_as_fp16: bool) -> None:
+        save_exr(filename, self.ReadResult(), save_as_fp16)
+
+    def destroy(self) -> None:
+        if self._m:
+            N.lib.adypt_destroy_multi(self._m)
+            self._m = C.c_void_p()
 
     def __del__(self) -> None:
         try:

@@ -219,14 +219,16 @@ __global__ __launch_bounds__(kShadeThreads) void k_store_cache(FrameArgs f, Queu
 	cache_of_group(f, px, frame_group(f, f.frame_first + ordinal * f.frame_stride))[L] = make_float4(h.x, h.y, h.z, 0.0f);
 }
 
-// Applies the finished samples of a batch to the running mean in frame order (pathtracer.glsl:224-226).
-__global__ __launch_bounds__(256) void k_resolve(FrameArgs f, SceneArgs sc, PixelArgs px)
+// Applies finished samples of a batch to the running mean in frame order (pathtracer.glsl:224-226): batch frames
+// [first, first + count); f.spp = index of the batch's first frame.  The whole batch at once, or — when the caller asks for
+// one frame per call and the batch was traced ahead (adypt_set_lookahead) — a few frames per call.
+__global__ __launch_bounds__(256) void k_resolve(FrameArgs f, SceneArgs sc, PixelArgs px, int first, int count)
 {
 	const int L = blockIdx.x * blockDim.x + threadIdx.x;
 	int x, y;
 	if(L >= f.n_local_px || !local_pixel_xy(f, sc.local_blocks, L, &x, &y)) return;
 	float4 acc = px.accum[L];
-	for(int k = 0; k < f.n_frames; ++k)
+	for(int k = first; k < first + count; ++k)
 	{
 		const float4 r = f.done[(size_t)k * f.n_local_px + L];
 		const float fs = (float)(f.spp + k), fs1 = (float)(f.spp + k + 1);

@@ -6,6 +6,7 @@
 //     queue sizes live in device memory, the traversal kernel is persistent, the shade grid covers the worst case)
 // There is no CPU fallback anywhere in this file: without a HIP device adypt_create fails with ADYPT_E_NO_DEVICE.
 #include "traverse.hpp"
+#include "ctx_access.hpp"
 #include "../../../include/adypt_hip.h"
 #include "../../../include/adypt_host.h"
 
@@ -92,10 +93,18 @@ struct adypt_ctx {
 	bool have_params = false, have_camera = false, pt_started = false;
 	float origin[3] = {0, 0, 0}, inv_proj[16] = {0}, inv_view[16] = {0};
 	int spp = 0;
+	// frames traced ahead (adypt_set_lookahead): the last wavefront batch covered frames [batch_spp, batch_spp + batch_frames);
+	// frames [batch_spp + ahead_pos, batch_spp + batch_frames) are finished samples parked in d_done, not yet in the image
+	int lookahead = 0, batch_spp = 0, batch_frames = 0, ahead_pos = 0, ahead_count = 0;
+	int cache_group = 0;        // which tmpLifetime group of that batch image 1 (d_cache) currently holds (0 = the batch's first)
 	uint32_t shift_seed_loaded = 0;
 	bool shift_loaded = false;
 	int instrumentation = 0;
 	int view_type = 0;          // uuViewer.uType of the image in d_accum: the viewer type of the last primary frame, 3 after path tracing
+
+	// RCCL communicator state of the native multi-GPU path (multi.hip owns and frees it)
+	void *comm = nullptr;
+	void (*comm_free)(void *) = nullptr;
 
 	std::vector<EventPair> events;
 	std::vector<EventPair> free_events;
@@ -441,7 +450,46 @@ int apply_params(adypt_ctx *c)
 	return load_shift(c);
 }
 
+// Running-mean step (pathtracer.glsl:224-226) of frames [first, first + count) of the batch last traced (its finished samples
+// are parked in d_done), in frame order; afterwards image 1 holds the primary hits of the tmpLifetime group of the last frame
+// applied — what frame-by-frame tracing leaves there (pathtracer.glsl:121-127).
+int resolve_batch_frames(adypt_ctx *c, const SceneArgs &sc, const PixelArgs &px, int first, int count)
+{
+	if(count <= 0) return ADYPT_OK;
+	FrameArgs f;
+	fill_frame(c, &f);
+	f.spp = c->batch_spp; f.n_frames = c->batch_frames;
+	hipEvent_t *stop = begin_timing(c, 1);
+	hipLaunchKernelGGL(k_resolve, dim3((c->n_local_px + 255) / 256), dim3(256), 0, c->stream, f, sc, px, first, count);
+	end_timing(c, stop);
+	HIP_TRY(c, hipGetLastError());
+	const int life = std::max(1, c->params.tmp_lifetime);
+	const int group = (c->batch_spp + first + count - 1) / life - c->batch_spp / life;
+	if(group > c->cache_group)
+	{
+		HIP_TRY(c, hipMemcpyAsync(c->d_cache, c->d_cache_next + (size_t)(group - 1) * (size_t)c->n_local_px, (size_t)c->n_local_px * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+		c->cache_group = group;
+	}
+	return ADYPT_OK;
+}
+
+// frames traced ahead belong to the camera / parameters / queues they were traced with: anything that changes those drops
+// them (they are re-traced on demand — the sample sequence is a function of the frame index alone)
+inline void drop_lookahead(adypt_ctx *c) { c->ahead_count = 0; c->ahead_pos = 0; }
+
 }  // namespace
+
+namespace adypt {
+CtxInfo ctx_info(adypt_ctx *c)
+{
+	CtxInfo i;
+	i.device = c->device; i.stream = c->stream; i.rank = c->rank; i.nranks = c->nranks; i.width = c->width; i.height = c->height;
+	i.n_local_px = c->n_local_px; i.accum = c->d_accum;
+	return i;
+}
+void ctx_set_error(adypt_ctx *c, const std::string &msg) { c->error = msg; }
+void **ctx_comm_slot(adypt_ctx *c, void (***free_fn)(void *)) { *free_fn = &c->comm_free; return &c->comm; }
+}  // namespace adypt
 
 extern "C" {
 
@@ -596,6 +644,8 @@ void adypt_destroy(adypt_ctx *c)
 	if(!c) return;
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
+	if(c->comm && c->comm_free) c->comm_free(c->comm);
+	c->comm = nullptr;
 	for(EventPair &p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
@@ -632,6 +682,7 @@ int adypt_set_camera(adypt_ctx *c, const float origin[3], const float inv_proj[1
 	if(!c || !origin || !inv_proj || !inv_view) return ADYPT_E_INVALID;
 	memcpy(c->origin, origin, 12); memcpy(c->inv_proj, inv_proj, 64); memcpy(c->inv_view, inv_view, 64);
 	c->have_camera = true;
+	drop_lookahead(c); // frames traced ahead saw the previous camera
 	return ADYPT_OK;
 }
 
@@ -640,8 +691,19 @@ int adypt_reset(adypt_ctx *c)
 	if(!c) return ADYPT_E_INVALID;
 	c->pt_started = false;
 	c->spp = 0;
+	drop_lookahead(c);
 	return ADYPT_OK;
 }
+
+int adypt_set_lookahead(adypt_ctx *c, int enabled)
+{
+	if(!c) return ADYPT_E_INVALID;
+	c->lookahead = enabled ? 1 : 0;
+	if(!enabled) drop_lookahead(c);
+	return ADYPT_OK;
+}
+
+int adypt_get_lookahead_frames(const adypt_ctx *c) { return c ? c->ahead_count : ADYPT_E_INVALID; }
 
 int adypt_get_spp(const adypt_ctx *c) { return c ? c->spp : ADYPT_E_INVALID; }
 
@@ -677,6 +739,7 @@ int adypt_set_sun_visibility(adypt_ctx *c, int enabled, const float dir[3])
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	c->sun_dir[0] = d[0] * inv; c->sun_dir[1] = d[1] * inv; c->sun_dir[2] = d[2] * inv;
 	c->sun_visibility = enabled ? 1 : 0;
+	drop_lookahead(c);
 	return ADYPT_OK;
 }
 
@@ -687,6 +750,7 @@ int adypt_set_frames_in_flight(adypt_ctx *c, int n)
 	HIP_TRY(c, hipSetDevice(c->device));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	if(n == c->frames_in_flight && c->queues_ok) return ADYPT_OK;
+	drop_lookahead(c); // the parked samples live in the buffers about to be reallocated
 	return alloc_queues(c, n);
 }
 
@@ -700,6 +764,7 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	HIP_TRY(c, hipSetDevice(c->device));
 	// Trace(false): leaves path-tracing mode (OglPathTracer.cpp:53-58)
 	c->pt_started = false; c->spp = 0;
+	drop_lookahead(c);
 	c->view_type = viewer_type;
 	int r = apply_params(c);
 	if(r != ADYPT_OK) return r;
@@ -767,6 +832,15 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 	const bool stats = (c->instrumentation & 2) != 0;
 	for(int remaining = n_spp; remaining > 0;)
 	{
+		if(c->ahead_count > 0)
+		{
+			// frames already traced ahead by an earlier call: only their running-mean step is left (frame order is kept)
+			const int k = std::min(remaining, c->ahead_count);
+			int r = resolve_batch_frames(c, sc, px, c->ahead_pos, k);
+			if(r != ADYPT_OK) return r;
+			c->ahead_pos += k; c->ahead_count -= k; c->spp += k; remaining -= k;
+			continue;
+		}
 		if(!c->pt_started)
 		{
 			// first path-traced frame (OglPathTracer.cpp:39-46): apply config, clear the result image, restart Sobol
@@ -782,7 +856,11 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		// running mean is applied afterwards in frame order, so the result is bit-identical to frame-by-frame).  A batch
 		// may span several tmpLifetime groups: the frames that re-trace their primary rays (spp % tmpLifetime == 0) run
 		// first, as one primary-only pass, and park their hits in the cache image of their group.
-		const int m = std::min(remaining, c->frames_in_flight);
+		// With look-ahead on, a call for fewer frames than fit in a pass (Instance::Update asks for ONE, src/Instance.cpp:44-57)
+		// still traces a full pass: frames are independent samples of a deterministic sequence, so the frames beyond the ones
+		// asked for are simply finished early and parked; later calls hand them out one running-mean step at a time.
+		const int m = c->lookahead ? c->frames_in_flight : std::min(remaining, c->frames_in_flight);
+		const int hand_out = std::min(remaining, m);
 		const int first_retrace = (life - c->spp % life) % life;                       // batch index of the first re-tracing frame
 		const int n_retrace = first_retrace < m ? (m - 1 - first_retrace) / life + 1 : 0;
 		const int n_groups = (c->spp + m - 1) / life - c->spp / life + 1;
@@ -864,18 +942,16 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 				end_timing(c, stop);
 			}
 		}
+		HIP_TRY(c, hipGetLastError());
 		if(m > 1)
 		{
-			hipEvent_t *stop = begin_timing(c, 1);
-			hipLaunchKernelGGL(k_resolve, dim3((c->n_local_px + 255) / 256), dim3(256), 0, c->stream, f, sc, px);
-			end_timing(c, stop);
-			// image 1 = the primary hits of the group the last frame belongs to (what frame-by-frame tracing leaves there)
-			if(n_groups > 1)
-				HIP_TRY(c, hipMemcpyAsync(c->d_cache, c->d_cache_next + (size_t)(n_groups - 2) * (size_t)c->n_local_px, (size_t)c->n_local_px * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+			c->batch_spp = c->spp; c->batch_frames = m; c->cache_group = 0;
+			int r = resolve_batch_frames(c, sc, px, 0, hand_out);
+			if(r != ADYPT_OK) return r;
+			c->ahead_pos = hand_out; c->ahead_count = m - hand_out;
 		}
-		HIP_TRY(c, hipGetLastError());
-		c->spp += m;
-		remaining -= m;
+		c->spp += hand_out;
+		remaining -= hand_out;
 	}
 	return ADYPT_OK; // everything is enqueued on the context's stream; adypt_wait collects errors and kernel timings
 }

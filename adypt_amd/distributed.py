@@ -104,3 +104,51 @@ def gather_radiance_device(local, tracer, width: int, height: int, rank: int, wo
     torch.cuda.current_stream(local.device).synchronize()  # the gather ran on torch's stream, the un-tiling runs on the tracer's
     tracer.assemble_radiance(gathered.data_ptr(), n // 4, rgb.data_ptr())
     return rgb
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Native path (no torch): the library's own RCCL communicator.  One process per GPU, launched by any launcher that sets
+# RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT (torch.distributed.run does); rank 0 makes the 128-byte RCCL id and the ranks
+# of the node exchange it through a file — the only thing the launcher's channel has to carry.
+# ---------------------------------------------------------------------------------------------------------------------
+def comm_unique_id() -> bytes:
+    import ctypes as C
+    buf = C.create_string_buffer(128)
+    N.check(N.lib.adypt_comm_unique_id(buf))
+    return buf.raw
+
+
+def rendezvous_path() -> str:
+    """One file per job: keyed by the launcher's port and run id so concurrent or repeated jobs never read a stale id."""
+    import os
+    import tempfile
+    key = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("ADYPT_RUN_ID", "none")))
+    return os.path.join(os.environ.get("ADYPT_RENDEZVOUS_DIR", tempfile.gettempdir()), "adypt_rccl_id_%s_%d" % (key, os.getppid()))
+
+
+def exchange_unique_id(rank: int, world: int, path: Optional[str] = None, make_id=comm_unique_id, timeout_s: float = 120.0) -> bytes:
+    """Rank 0 writes the id (atomic rename), the others wait for the file.  Single node only (shared /tmp)."""
+    import os
+    import time
+    path = path or rendezvous_path()
+    if world == 1:
+        return make_id()
+    if rank == 0:
+        uid = make_id()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except OSError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError("no RCCL id from rank 0 at %s after %.0f s" % (path, timeout_s))
+        time.sleep(0.01)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ADYPT_ABI_VERSION 1
+#define ADYPT_ABI_VERSION 2
 
 enum adypt_status {
 	ADYPT_OK = 0,
@@ -137,6 +137,17 @@ int adypt_get_spp(const adypt_ctx *ctx); /* OglPathTracer::GetSPP */
  * the trace calls return ADYPT_E_STATE. */
 int adypt_set_frames_in_flight(adypt_ctx *ctx, int n_frames);
 int adypt_get_frames_in_flight(const adypt_ctx *ctx);
+/* Look-ahead for callers that ask for ONE frame per call, as Instance::Update does (src/Instance.cpp:44-57 -> Trace(true),
+ * src/Tracer/OglPathTracer.cpp:34-61).  Off (default): adypt_trace_spp(ctx, n) traces exactly n frames.  On: a call that
+ * needs frames not traced yet traces a whole pass of frames_in_flight frames — frame k's sample depends only on k (Sobol
+ * point k, per-pixel shift, the sub-pixel offset and primary-hit cache of its tmpLifetime group), so the extra frames are
+ * the very samples later calls would compute — applies the running mean for the n frames asked for, and parks the rest;
+ * the following calls only apply one running-mean step per frame.  The image, adypt_get_spp and image 1 (adypt_read_hits)
+ * after every call are bit-identical to frame-by-frame tracing; adypt_get_stats counts work when it is done, i.e. includes
+ * frames traced ahead.  adypt_set_camera, adypt_reset, adypt_trace_primary, adypt_set_sun_visibility and
+ * adypt_set_frames_in_flight drop the parked frames (they are traced again, with the new state, when asked for). */
+int adypt_set_lookahead(adypt_ctx *ctx, int enabled);
+int adypt_get_lookahead_frames(const adypt_ctx *ctx); /* frames currently parked */
 
 /* glGetTextureImage(m_result_tex, GL_RGB, GL_FLOAT) of OglPathTracer::SaveResult (OglPathTracer.cpp:203-205):
  * W*H*3 floats, row 0 = top of the image.  Pixels of blocks this context does not own are left untouched. */
@@ -184,6 +195,57 @@ int adypt_assemble_radiance(adypt_ctx *ctx, const void *gathered_device, int64_t
 int64_t adypt_shard_block_count(int width, int height, int rank, int nranks);
 /* scatter one rank's compact buffer (host memory, block-major float4) into a W*H*3 host image */
 int adypt_untile_host(int width, int height, int rank, int nranks, const float *local_rgba, float *rgb);
+
+/* ---- native multi-GPU (SURVEY.md §8b "Inputs: device_ids[], n_dev" / §8e): RCCL inside the library -----------------------
+ * The frame shards by 32x32 pixel tile with no data-path collective; the ONE exchange is the gather of the fp32 radiance
+ * tiles on the root GPU per output frame — grouped ncclSend / ncclRecv with the exact per-rank sizes (the equivalent of
+ * one ncclGather, rccl.h:745, without padding), each peer -> root over its own xGMI link, followed by the un-tiling kernel
+ * on the root.  librccl is loaded on first use (dlopen), so the library itself has no link-time dependency on it.
+ *
+ * (1) One process, N devices — what a C++ host such as the reference's Instance (src/Instance.cpp:33-57) needs to use more
+ * than one GPU: one adypt_multi stands for N contexts (tile rank i on device_ids[i], scene replicated), every call fans out
+ * to all of them from the calling thread (the per-device work is asynchronous), adypt_multi_read_radiance gathers. */
+typedef struct adypt_multi adypt_multi;
+int adypt_create_multi(adypt_multi **out, const adypt_scene_desc *desc /* device, tile_rank, tile_nranks ignored */,
+                       const int *device_ids, int n_dev);
+void adypt_destroy_multi(adypt_multi *m);
+const char *adypt_multi_last_error(const adypt_multi *m); /* m may be NULL: error of the last failed adypt_create_multi */
+int adypt_multi_device_count(const adypt_multi *m);
+adypt_ctx *adypt_multi_context(adypt_multi *m, int i);    /* the context of device_ids[i] (statistics, tunables); owned by m */
+int adypt_multi_set_params(adypt_multi *m, const adypt_pt_params *params);
+int adypt_multi_set_camera(adypt_multi *m, const float origin[3], const float inv_proj[16], const float inv_view[16]);
+int adypt_multi_set_lookahead(adypt_multi *m, int enabled);
+int adypt_multi_trace_primary(adypt_multi *m, int viewer_type);
+int adypt_multi_trace_spp(adypt_multi *m, int n_spp);     /* all devices enqueue, then all are waited for */
+int adypt_multi_reset(adypt_multi *m);
+int adypt_multi_get_spp(const adypt_multi *m);
+/* glGetTextureImage of OglPathTracer::SaveResult (OglPathTracer.cpp:203-205) for the whole image: the gather + un-tiling on
+ * device_ids[0], then one device-to-host copy of W*H*3 floats (row 0 = top). */
+int adypt_multi_read_radiance(adypt_multi *m, float *rgb);
+/* the same, leaving the assembled W*H*3 fp32 image in the HBM of device_ids[0] (library-owned buffer, valid until the next
+ * gather or adypt_destroy_multi) — resident like the reference's result texture */
+int adypt_multi_gather_radiance(adypt_multi *m, void **rgb_device);
+/* creates the RCCL communicators now (otherwise: at the first gather, and only when n_dev > 1); lets a caller — and the
+ * one-GPU test — find out at start-up whether RCCL is usable */
+int adypt_multi_comm_init(adypt_multi *m);
+
+/* (2) One process per GPU (launchers that fork a rank per device): every rank creates its context with tile_rank = rank,
+ * tile_nranks = world; rank 0 makes an id, the launcher's own channel (a file, MPI, a socket) carries its 128 bytes to the
+ * other ranks, every rank calls adypt_comm_init.  The calls below are collective over the ranks of the shard. */
+#define ADYPT_COMM_ID_BYTES 128
+int adypt_comm_unique_id(char id[ADYPT_COMM_ID_BYTES]);
+int adypt_comm_init(adypt_ctx *ctx, const char id[ADYPT_COMM_ID_BYTES]);
+/* the one gather: on rank 0 *rgb_device = assembled W*H*3 fp32 image in HBM (library-owned), elsewhere NULL; returns after
+ * the context's stream has drained */
+int adypt_comm_gather_radiance(adypt_ctx *ctx, void **rgb_device);
+/* gather + copy to host memory on rank 0 (rgb may be NULL on the other ranks) */
+int adypt_comm_read_radiance(adypt_ctx *ctx, float *rgb);
+/* control-plane helpers for launchers without a communication layer of their own (bench.py): in-place all-reduce of n
+ * doubles (op 0 = sum, 1 = max), and a barrier (= all-reduce of one value + stream drain) */
+int adypt_comm_allreduce(adypt_ctx *ctx, double *values, int n, int op);
+int adypt_comm_barrier(adypt_ctx *ctx);
+/* blocks until everything enqueued on the context's device has finished (hipDeviceSynchronize on its device) */
+int adypt_device_synchronize(adypt_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -44,7 +44,7 @@ private:
 	};
 	static_assert(sizeof(GPUMaterial) == 64, "material record layout");
 
-	adypt_ctx *m_ctx = nullptr;
+	adypt_multi *m_gpus = nullptr; // one tile shard per device; a single device is the n_dev = 1 case of the same calls
 	const InstanceConfig::PT *m_config = nullptr;
 	int m_width = 0, m_height = 0;
 	std::vector<GPUMaterial> m_materials;
@@ -93,7 +93,7 @@ private:
 #else
 		p.shift_seed = std::random_device{}();
 #endif
-		return adypt_set_params(m_ctx, &p) == ADYPT_OK;
+		return adypt_multi_set_params(m_gpus, &p) == ADYPT_OK;
 	}
 
 public:
@@ -102,12 +102,15 @@ public:
 	HipPathTracer &operator=(const HipPathTracer &) = delete;
 	~HipPathTracer()
 	{
-		adypt_destroy(m_ctx);
+		adypt_destroy_multi(m_gpus);
 		for(unsigned char *p : m_texture_pixels) stbi_image_free(p);
 	}
 
-	// OglScene::Initialize(scene, bvh) + OglPathTracer::Initialize(config, oglscene, width, height)
-	bool Initialize(const InstanceConfig::PT *config, const Scene &scene, const WideBVH &bvh, int width, int height, int device = 0)
+	// OglScene::Initialize(scene, bvh) + OglPathTracer::Initialize(config, oglscene, width, height).
+	// devices: HIP device ordinals; with more than one the frame is sharded by 32x32 pixel tile over them (scene replicated,
+	// no communication while rendering) and SaveResult gathers the radiance on devices[0] over RCCL.
+	bool Initialize(const InstanceConfig::PT *config, const Scene &scene, const WideBVH &bvh, int width, int height,
+	                const std::vector<int> &devices = std::vector<int>(1, 0))
 	{
 		m_config = config; m_width = width; m_height = height;
 		init_materials(scene);
@@ -119,15 +122,18 @@ public:
 		d.triangles = scene.GetTriangles().data();  d.n_tris = (int64_t)scene.GetTriangles().size();
 		d.materials = m_materials.data();           d.n_mats = (int64_t)m_materials.size();
 		d.textures = m_textures.data();             d.n_textures = (int32_t)m_textures.size();
-		d.width = width; d.height = height; d.device = device; d.tile_rank = 0; d.tile_nranks = 1;
-		if(adypt_create(&m_ctx, &d) != ADYPT_OK) { printf("[PT]ERR: %s\n", adypt_last_error(nullptr)); return false; }
+		d.width = width; d.height = height;
+		if(adypt_create_multi(&m_gpus, &d, devices.data(), (int)devices.size()) != ADYPT_OK) { printf("[PT]ERR: %s\n", adypt_multi_last_error(nullptr)); return false; }
+		// Instance::Update calls Trace(true) once per window frame: let the library trace a whole wavefront pass on the first
+		// call and hand the finished frames out one per call (bit-identical images, adypt_hip.h adypt_set_lookahead)
+		adypt_multi_set_lookahead(m_gpus, 1);
 		return update_config_args();
 	}
 
 	void SetCamera(const glm::mat4 &projection, const glm::mat4 &view, const glm::vec3 &position)
 	{
 		const glm::mat4 inv_projection = glm::inverse(projection), inv_view = glm::inverse(view);
-		adypt_set_camera(m_ctx, &position.x, &inv_projection[0][0], &inv_view[0][0]);
+		adypt_multi_set_camera(m_gpus, &position.x, &inv_projection[0][0], &inv_view[0][0]);
 	}
 
 	// Trace(true): one more sample per pixel; Trace(false): one primary-ray viewer frame and the sample counter restarts
@@ -135,30 +141,32 @@ public:
 	{
 		if(enable_pt)
 		{
-			if(adypt_get_spp(m_ctx) == 0) update_config_args(); // the config is re-read when path tracing (re)starts
+			if(adypt_multi_get_spp(m_gpus) == 0) update_config_args(); // the config is re-read when path tracing (re)starts
 			m_viewer_type = kPTRadiance;
-			if(adypt_trace_spp(m_ctx, 1) != ADYPT_OK) printf("[PT]ERR: %s\n", adypt_last_error(m_ctx));
+			if(adypt_multi_trace_spp(m_gpus, 1) != ADYPT_OK) printf("[PT]ERR: %s\n", adypt_multi_last_error(m_gpus));
 		}
 		else
 		{
 			if(m_viewer_type == kPTRadiance) m_viewer_type = kDiffuse;
-			if(adypt_trace_primary(m_ctx, m_viewer_type) != ADYPT_OK) printf("[PT]ERR: %s\n", adypt_last_error(m_ctx));
+			if(adypt_multi_trace_primary(m_gpus, m_viewer_type) != ADYPT_OK) printf("[PT]ERR: %s\n", adypt_multi_last_error(m_gpus));
 		}
 	}
 
-	int GetSPP() const { return adypt_get_spp(m_ctx); }
+	int GetSPP() const { return adypt_multi_get_spp(m_gpus); }
 
-	// what DrawScreen puts on screen, for a caller-owned W x H RGBA8 texture / window
+	// what DrawScreen puts on screen, for a caller-owned W x H RGBA8 texture / window (every device fills in its own tiles)
 	bool ReadScreen(std::vector<uint8_t> *rgba8) const
 	{
 		rgba8->resize((size_t)m_width * m_height * 4);
-		return adypt_read_display(m_ctx, rgba8->data()) == ADYPT_OK;
+		for(int i = 0; i < adypt_multi_device_count(m_gpus); ++i)
+			if(adypt_read_display(adypt_multi_context(m_gpus, i), rgba8->data()) != ADYPT_OK) return false;
+		return true;
 	}
 
 	void SaveResult(const char *filename, bool save_as_fp16)
 	{
 		std::vector<float> pixels((size_t)m_width * m_height * 3);
-		if(adypt_read_radiance(m_ctx, pixels.data()) != ADYPT_OK) { printf("[PT]ERR: %s\n", adypt_last_error(m_ctx)); return; }
+		if(adypt_multi_read_radiance(m_gpus, pixels.data()) != ADYPT_OK) { printf("[PT]ERR: %s\n", adypt_multi_last_error(m_gpus)); return; }
 		const char *err = nullptr;
 		if(SaveEXR(pixels.data(), m_width, m_height, 3, save_as_fp16, filename, &err) < 0)
 		{

@@ -87,3 +87,25 @@ def test_ownership_partitions_the_image():
         for r in range(n):
             D.untile(w, h, r, n, D.tile_from_image(img, r, n), rgb)
         assert np.array_equal(rgb, img[..., :3])
+
+
+def _rendezvous_worker(rank, world, path, q):
+    from adypt_amd import distributed as D
+    uid = D.exchange_unique_id(rank, world, path=path, make_id=lambda: bytes(range(128)), timeout_s=30.0)
+    q.put((rank, uid))
+
+
+def test_native_rendezvous_file_carries_the_id_between_processes(tmp_path):
+    """The native (torch-free) multi-process path exchanges ONE thing outside RCCL: the 128-byte communicator id, through a
+    file written atomically by rank 0.  RCCL itself needs GPUs; the exchange is checked here with a stand-in id."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    path = str(tmp_path / "id")
+    procs = [ctx.Process(target=_rendezvous_worker, args=(r, 3, path, q)) for r in (2, 1, 0)]  # readers start first
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert got == {0: bytes(range(128)), 1: bytes(range(128)), 2: bytes(range(128))}

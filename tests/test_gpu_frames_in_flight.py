@@ -53,3 +53,75 @@ def test_frames_in_flight_is_bit_invariant(name, w, h, life, spp, scene_cache, s
             ref_tri, ref_uv = tri, uv
         else:
             assert np.array_equal(tri, ref_tri) and np.array_equal(bits(uv), bits(ref_uv))
+
+
+@pytest.mark.parametrize("name,w,h,life,fif", [("tiny0", 100, 75, 4, 13), ("tiny0", 96, 64, 16, 32), ("sibenik", 160, 90, 3, 8), ("tiny0", 72, 40, 1, 5)])
+def test_lookahead_hands_out_identical_frames_one_per_call(name, w, h, life, fif, scene_cache, sobol_matrices):
+    """adypt_set_lookahead: Instance::Update's pattern — ONE Trace(true) per call (src/Instance.cpp:44-57) — served from
+    whole wavefront passes traced ahead.  After EVERY call the image, the spp counter and image 1 (primary-hit cache) equal
+    what the oracle's frame-by-frame loop has after that frame; a camera change / reset drops the parked frames."""
+    inst = _instance(scene_cache, name, w, h, {"tmpLifetime": life, "maxBounce": 6, "subpixel": 3})
+    c, p = inst.m_config.c, inst.m_path_tracer
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    shift = O.shift_bytes(31, c.width, c.height)
+    p.SetFramesInFlight(fif)
+    p.SetLookahead(True)
+    state = O.PathTracerState(c.width, c.height)
+    total = 2 * fif + 3
+    for k in range(total):
+        p.Trace(True, 1)
+        O.pt_frames(osc, P, shift, sobol_matrices, state, 1)
+        assert p.GetSPP() == k + 1
+        assert p.GetLookaheadFrames() == (fif - 1 - k % fif)
+        assert np.array_equal(bits(p.ReadResult()), bits(state.accum[..., :3])), "frame %d" % k
+        tri, uv = p.ReadHits()
+        assert np.array_equal(tri, state.cache_tri), "image 1 after frame %d" % k
+        m = tri >= 0
+        assert np.array_equal(bits(uv)[m], bits(state.cache_uv)[m])
+    # mixed call sizes continue the same sequence (parked frames + a new pass + ...)
+    p.Trace(True, fif + 2)
+    O.pt_frames(osc, P, shift, sobol_matrices, state, fif + 2)
+    assert np.array_equal(bits(p.ReadResult()), bits(state.accum[..., :3])) and p.GetSPP() == total + fif + 2
+    n = p.GetLookaheadFrames()
+    p.Trace(True, n)
+    if n:
+        O.pt_frames(osc, P, shift, sobol_matrices, state, n)
+    assert p.GetLookaheadFrames() == 0 and np.array_equal(bits(p.ReadResult()), bits(state.accum[..., :3]))
+    # a camera change drops the parked frames: the next frame is traced with the new camera, the cache image keeps the old
+    # primary hits until the next re-tracing frame — exactly the reference's behaviour (pathtracer.glsl:113-127)
+    p.Trace(True, 1)
+    O.pt_frames(osc, P, shift, sobol_matrices, state, 1)
+    assert p.GetLookaheadFrames() == fif - 1
+    ip, iv = O.camera(c.fov + 7.0, c.yaw + 11.0, c.pitch - 3.0, c.width, c.height)
+    p.SetCamera(ip, iv, list(c.position))
+    assert p.GetLookaheadFrames() == 0
+    P2 = O.make_params(c.width, c.height, list(c.position), ip, iv, stack_size=c.stack_size, max_bounce=c.max_bounce, subpixel=c.subpixel,
+                       tmp_life=c.tmp_lifetime, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))
+    for k in range(life + 2):
+        p.Trace(True, 1)
+        O.pt_frames(osc, P2, shift, sobol_matrices, state, 1)
+        assert np.array_equal(bits(p.ReadResult()), bits(state.accum[..., :3])), "after camera change, frame %d" % k
+    # reset restarts the sequence
+    p.Reset()
+    assert p.GetLookaheadFrames() == 0
+    p.Trace(True, 2)
+    st2 = O.PathTracerState(c.width, c.height)
+    O.pt_frames(osc, P2, shift, sobol_matrices, st2, 2)
+    assert np.array_equal(bits(p.ReadResult()), bits(st2.accum[..., :3]))
+
+
+def test_lookahead_work_counters_match_after_full_hand_out(scene_cache, sobol_matrices):
+    inst = _instance(scene_cache, "tiny0", 96, 64, {"tmpLifetime": 4, "maxBounce": 6, "subpixel": 3})
+    c, p = inst.m_config.c, inst.m_path_tracer
+    p.SetFramesInFlight(8)
+    p.SetLookahead(True)
+    p.SetInstrumentation(counters=True)
+    p.ResetStats()
+    for _ in range(16):
+        p.Trace(True, 1)
+    assert p.GetLookaheadFrames() == 0
+    state = O.PathTracerState(c.width, c.height)
+    ost = O.pt_frames(oracle_scene_from_instance(inst), oracle_params_from_config(c), O.shift_bytes(31, c.width, c.height), sobol_matrices, state, 16).as_dict()
+    st = p.GetStats()
+    assert (st["rays"], st["nodes_visited"], st["tris_tested"], st["shaded"]) == (ost["rays"], ost["nodes"], ost["tris"], ost["shaded"])
+    assert np.array_equal(bits(p.ReadResult()), bits(state.accum[..., :3]))
