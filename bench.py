@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the hot path (BASELINE.json): Mrays/s (primary + secondary) of the wavefront
-path tracer on the Sponza-class scene, 1920x1080, 8 bounces, with the % of the HBM-read roofline of the dominant
-kernel (the CWBVH8 traversal) and a CPU baseline (the oracle's scalar traversal) timed on the same box.
+path tracer on the Sponza-class scene, 1920x1080, 8 bounces, with the roofline of the dominant kernel (the CWBVH8
+traversal) and a CPU baseline (the oracle's scalar traversal) timed on the same box.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -9,7 +9,20 @@ kernel (the CWBVH8 traversal) and a CPU baseline (the oracle's scalar traversal)
 One "step" = one path-traced frame (1 spp) of the whole 1920x1080 image = one pass of the hot path over one batch:
 camera rays -> [traversal -> shade/scatter] x 8 -> accumulate.  With N > 1 the frame is sharded by 32x32 pixel tile
 over the ranks (zero communication while rendering) and the timed region ends with the single gather of the fp32
-radiance on rank 0 (RCCL over xGMI).  Total work is fixed as N grows -> "scaling": "strong".
+radiance on rank 0 (RCCL over xGMI, inside the library: adypt_comm_gather_radiance).  Total work is fixed as N grows ->
+"scaling": "strong".  The launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT: the product needs no torch
+(`--comm torch` keeps the torch.distributed variant: barrier / reductions / gather through torch, backend nccl = RCCL).
+
+What the JSON line carries besides the contract's fields:
+  roofline               the traversal kernel on the bench scene.  Its BVH (19 MB) is cache resident, so the HBM roof does not
+                         bind; the kernel is bound by vector-ALU issue -> bound "valu_issue", achieved = issued wave-instructions
+                         per second (PMC count per ray x measured rays/s of the kernel) against 1024 SIMDs x 1 instruction / 4
+                         cycles x 2.4 GHz; lane_util = fraction of the 64 lanes doing work in an issued instruction.  The
+                         algorithmic HBM-read figure of SURVEY.md §8(d) and the measured fabric traffic are reported next to it.
+  roofline_hbm_resident  the same kernel on the ~10 M-triangle stand-in of BASELINE config 4 (BVH 0.6 GB > 256 MB Infinity
+                         Cache): here HBM binds -> bound "hbm", algorithmic bytes / HIP-event time / 8 TB/s.
+  single_frame           one adypt_trace_spp(ctx, 1) per call (what Instance::Update does), with the library's look-ahead.
+  cpu_baseline           oracle/liboracle.so on the host cores, bounded sample.
 
 Scene: the real sponza.obj is not available anywhere (no network); a deterministic procedural stand-in of the same
 triangle count is generated, written as OBJ/MTL + Adypt .config and loaded through the product's own
@@ -26,7 +39,107 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec)
+VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0  # 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles (16 lanes/clk for fp32 and integer
+                                     # ops; only v_pk_* do two per lane), 2.4 GHz: 614.4 G wave-instructions/s
+PT_CFG = {"maxBounce": 8, "subpixel": 8, "clamp": 4.0, "sun": [12.0, 11.0, 10.0], "stackSize": 24}
+SEED = 12345
+
+
+def load_profile(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return None
+
+
+def census(pt, steps, warmup, expect_rays=None):
+    """The same K frames again through the instrumented traversal -> exact node / triangle counts -> algorithmic bytes
+    (per ray 80 B x nodes visited + 48 B x triangles tested + 4 B x hit remap + 32 B ray read + 16 B hit write)."""
+    pt.Reset()
+    pt.SetInstrumentation(timing=False, counters=True)
+    if warmup:
+        pt.Trace(True, warmup)
+    pt.ResetStats()
+    pt.Trace(True, steps)
+    cs = pt.GetStats()
+    pt.SetInstrumentation(False, False)
+    if expect_rays is not None:
+        assert cs["rays"] == expect_rays, "census pass traced a different number of rays"
+    cs["alg_bytes"] = 80 * cs["nodes_visited"] + 48 * cs["tris_tested"] + 4 * cs["hits"] + 48 * cs["rays"]
+    return cs
+
+
+def hbm_resident_block(args, dev):
+    """roofline_hbm_resident: the traversal kernel where HBM binds (BASELINE config 4 stand-in, BVH 0.6 GB)."""
+    from adypt_amd import api, scenes
+    t0 = time.time()
+    spec = scenes.make_scene("sanmiguel", args.cache, width=1920, height=1080, pt=dict(PT_CFG, tmpLifetime=16))
+    inst = api.Instance()
+    assert inst.InitializeFromFile(spec.config_path, shift_seed=SEED, device=dev), api.InstanceConfig.last_error()
+    setup_s = time.time() - t0
+    pt = inst.m_path_tracer
+    steps, warmup = 32, 16
+    pt.SetInstrumentation(timing=True, counters=False)
+    pt.Trace(True, warmup)
+    pt.ResetStats()
+    t1 = time.perf_counter()
+    pt.Trace(True, steps)
+    wall = time.perf_counter() - t1
+    st = pt.GetStats()
+    cs = census(pt, steps, warmup, st["rays"])
+    bvh_mb = (len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 52) / 1e6
+    achieved = cs["alg_bytes"] / (st["trace_ms"] * 1e-3) / 1e9
+    out = {"bound": "hbm", "kernel": "k_trace<false, false>",
+           "workload": "sanmiguel-like procedural stand-in (%s), %d triangles, BVH %.0f MB (nodes + Woop + index) > 256 MB Infinity Cache, 1920x1080, 8 bounces, %d frames after %d warm-up"
+                       % (spec.label, inst.scene.n_tris, bvh_mb, steps, warmup),
+           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+           "launches": int(st["trace_launches"]), "avg_launch_ms": round(st["trace_ms"] / max(1, st["trace_launches"]), 4),
+           "alg_bytes_per_launch": round(cs["alg_bytes"] / max(1, st["trace_launches"])), "alg_bytes_per_ray": round(cs["alg_bytes"] / cs["rays"], 1),
+           "nodes_per_ray": round(cs["nodes_visited"] / cs["rays"], 2), "tris_per_ray": round(cs["tris_tested"] / cs["rays"], 2),
+           "trace_kernel_Mrays_s": round(st["rays"] / (st["trace_ms"] * 1e3), 1), "whole_frame_Mrays_s": round(st["rays"] / wall / 1e6, 1),
+           "trace_kernels_ms": round(st["trace_ms"], 2), "shade_kernels_ms": round(st["shade_ms"], 2), "setup_s": round(setup_s, 1)}
+    pmc = load_profile("r2_pmc_sanmiguel.json")
+    if pmc and "traffic_bytes_per_ray" in pmc:
+        out["traffic"] = round(pmc["traffic_bytes_per_ray"] * st["rays"] / max(1, st["trace_launches"]))
+        out["traffic_GBs"] = round(pmc["traffic_bytes_per_ray"] * st["rays"] / (st["trace_ms"] * 1e-3) / 1e9, 1)
+        out["traffic_over_algorithmic"] = round(pmc["traffic_bytes_per_ray"] / (cs["alg_bytes"] / cs["rays"]), 3)
+        out["traffic_source"] = "profiles/r2_pmc_sanmiguel.json: %.1f fabric bytes per ray (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, separate rocprofv3 --pmc passes of %s) x the rays per launch of this run" % (
+            pmc["traffic_bytes_per_ray"], pmc.get("command", "bench.py --scene sanmiguel"))
+    pt.destroy()
+    return out
+
+
+def cpu_baseline(inst, c):
+    """The oracle's scalar traversal + shading of the same workload on the host cores, bounded sample (kind "port")."""
+    from oracle import oracle_py as O
+    osc = O.Scene(inst.bvh.nodes, inst.bvh.tri_indices, inst.scene.triangles, inst.scene.materials, textures=inst.scene.textures)
+    ip, iv = O.camera(c.fov, c.yaw, c.pitch, c.width, c.height)
+    P = O.make_params(c.width, c.height, list(c.position), ip, iv, stack_size=c.stack_size, max_bounce=c.max_bounce, subpixel=c.subpixel,
+                      tmp_life=1, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))
+    sm = np.fromfile(os.path.join(ROOT, "tests", "golden", "sobol_matrices_64x32.u32"), dtype=np.uint32).reshape(64, 32)
+    cores = O.default_threads()
+    stc = O.PathTracerState(c.width, c.height)
+    shift = O.shift_bytes(SEED, c.width, c.height)
+    cpu_rays, cpu_t, frames = 0, 0.0, 0
+    while cpu_t < 10.0 and frames < 16:
+        t1 = time.perf_counter()
+        s = O.pt_frames(osc, P, shift, sm, stc, 1, n_threads=cores)
+        cpu_t += time.perf_counter() - t1
+        cpu_rays += s.rays
+        frames += 1
+    # one thread (SURVEY.md §8d asks for both): a quarter-height frame keeps it to a few seconds
+    P1 = O.make_params(c.width, c.height // 4, list(c.position), *O.camera(c.fov, c.yaw, c.pitch, c.width, c.height // 4), stack_size=c.stack_size,
+                       max_bounce=c.max_bounce, subpixel=c.subpixel, tmp_life=1, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))
+    st1 = O.PathTracerState(c.width, c.height // 4)
+    t1 = time.perf_counter()
+    s1 = O.pt_frames(osc, P1, O.shift_bytes(SEED, c.width, c.height // 4), sm, st1, 1, n_threads=1)
+    t1 = time.perf_counter() - t1
+    return {"value": round(cpu_rays / cpu_t / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d full %dx%d frames (every frame traces its primaries), %d rays, %.1f s, oracle/liboracle.so on %d threads"
+                      % (frames, c.width, c.height, cpu_rays, cpu_t, cores),
+            "value_1_thread": round(s1.rays / t1 / 1e6, 3),
+            "sample_1_thread": "one %dx%d frame, %d rays, %.1f s" % (c.width, c.height // 4, s1.rays, t1)}
 
 
 def main() -> None:
@@ -38,23 +151,27 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tmp-lifetime", type=int, default=16, help="reference default 16: primary hits are re-traced every 16th frame")
+    ap.add_argument("--comm", default=os.environ.get("ADYPT_BENCH_COMM", "native"), choices=["native", "torch"],
+                    help="N > 1: 'native' = the library's own RCCL communicator (no torch); 'torch' = torch.distributed (nccl, or gloo with ADYPT_BENCH_BACKEND=gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-block", action="store_true", help="skip roofline_hbm_resident (the 10 M-triangle scene: ~25 s of setup)")
+    ap.add_argument("--no-single-frame", action="store_true")
     ap.add_argument("--cache", default=os.environ.get("ADYPT_CACHE", os.path.join(ROOT, ".adypt_cache")))
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    dev = local_rank % max(1, torch.cuda.device_count())  # == local_rank on a real multi-GPU node
-    torch.cuda.set_device(dev)
-    if world > 1:
+    use_torch = world > 1 and args.comm == "torch"
+    dev = local_rank
+    dist = torch = None
+    if use_torch:
+        import torch
+        import torch.distributed as dist
+        dev = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("ADYPT_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse the N>1 flow on a 1-GPU box
         if backend == "nccl":
@@ -62,45 +179,57 @@ def main() -> None:
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from adypt_amd import api, distributed as D, scenes
+    from adypt_amd import api, distributed as D, scenes, _native as N
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    # ---- scene: rank 0 generates + builds the BVH cache, the others load it ------------------------------------
-    pt_cfg = {"maxBounce": 8, "subpixel": 8, "tmpLifetime": args.tmp_lifetime, "clamp": 4.0, "sun": [12.0, 11.0, 10.0], "stackSize": 24}
+    # ---- scene: every rank generates + builds its own copy (0.8 s; nothing to wait for, no shared cache to race on) ------------
+    pt_cfg = dict(PT_CFG, tmpLifetime=args.tmp_lifetime)
+    cache = args.cache if world == 1 else os.path.join(args.cache, "rank%d" % rank)
     t_setup = time.time()
+    spec = scenes.make_scene(args.scene, cache, width=args.width, height=args.height, pt=pt_cfg)
     inst = api.Instance()
-    if rank == 0:
-        spec = scenes.make_scene(args.scene, args.cache, width=args.width, height=args.height, pt=pt_cfg)
-        ok = inst.InitializeFromFile(spec.config_path, shift_seed=12345, device=dev, tile_rank=rank, tile_nranks=world)
-        assert ok, api.InstanceConfig.last_error()
-    barrier()
-    if rank != 0:
-        spec = scenes.make_scene(args.scene, args.cache, width=args.width, height=args.height, pt=pt_cfg)
-        ok = inst.InitializeFromFile(spec.config_path, shift_seed=12345, device=dev, tile_rank=rank, tile_nranks=world)
-        assert ok, api.InstanceConfig.last_error()
+    try:
+        ok = inst.InitializeFromFile(spec.config_path, shift_seed=SEED, device=dev, tile_rank=rank, tile_nranks=world)
+    except N.AdyptError as e:
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path (%s)" % e)
+    assert ok, api.InstanceConfig.last_error()
     pt = inst.m_path_tracer
     c = inst.m_config.c
+    fif = pt.GetFramesInFlight()
     t_setup = time.time() - t_setup
-    n_pad = D.max_block_count(c.width, c.height, world) * D.BLOCK_PIXELS * 4
-    gather_buf = torch.zeros(n_pad, dtype=torch.float32, device="cuda")
+
+    if use_torch:
+        n_pad = D.max_block_count(c.width, c.height, world) * D.BLOCK_PIXELS * 4
+        gather_buf = torch.zeros(n_pad, dtype=torch.float32, device="cuda")
+        on_device = dist.get_backend() == "nccl"  # gloo rehearsal: host tensors, host un-tiling
+
+        def barrier():
+            torch.cuda.synchronize()
+            dist.barrier()
+
+        def gather():
+            pt.copy_local_radiance(gather_buf.data_ptr(), n_pad // 4)
+            if on_device:
+                return D.gather_radiance_device(gather_buf, pt, c.width, c.height, rank, world)
+            return D.gather_radiance(gather_buf, c.width, c.height, rank, world)
+    else:
+        if world > 1:
+            pt.CommInit(D.exchange_unique_id(rank, world))  # the ranks' only exchange outside RCCL: the 128-byte communicator id
+
+        def barrier():
+            # every rank's GPU drained (hipDeviceSynchronize), then all ranks met (RCCL all-reduce + drain)
+            pt.DeviceSynchronize()
+            if world > 1:
+                pt.CommBarrier()
+
+        def gather():
+            return pt.CommGatherDevice()  # the one collective of the data path; rank 0: the assembled image, resident in HBM
 
     # ---- warmup ------------------------------------------------------------------------------------------------------
     pt.SetInstrumentation(timing=True, counters=False)
     if args.warmup:
         pt.Trace(True, args.warmup)
-    on_device = world == 1 or dist.get_backend() == "nccl"  # gloo rehearsal: host tensors, host un-tiling
-
-    def gather():
-        pt.copy_local_radiance(gather_buf.data_ptr(), n_pad // 4)
-        if on_device:
-            return D.gather_radiance_device(gather_buf, pt, c.width, c.height, rank, world)
-        return D.gather_radiance(gather_buf, c.width, c.height, rank, world)
-
     gather()  # warms the communicator
+    rays_warmup = int(pt.GetStats()["rays"])
     pt.ResetStats()
 
     # ---- timed region: exactly K steps + the one gather ------------------------------------------------------------
@@ -112,88 +241,99 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     gather_ms = (time.perf_counter() - t_gather) * 1e3
-    if image is not None and on_device:
-        image = image.cpu().numpy()
     st = pt.GetStats()
-    red_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    rays = torch.tensor([int(st["rays"])], dtype=torch.int64, device=red_dev)
-    if world > 1:
+    if use_torch:
+        if image is not None and on_device:
+            image = image.cpu().numpy()
+        red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        rays = torch.tensor([int(st["rays"])], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-    elapsed = float(tt.item())
-    total_rays = int(rays.item())
+        elapsed, total_rays = float(tt.item()), int(rays.item())
+    else:
+        if world > 1:
+            elapsed = pt.CommAllReduce([elapsed], "max")[0]          # MAX over ranks
+            total_rays = int(round(pt.CommAllReduce([float(st["rays"])], "sum")[0]))  # exact: < 2^53
+        else:
+            total_rays = int(st["rays"])
+        image = pt.CommReadResult()  # untimed (collective): the image on the host for the checksum
 
     # ---- census (untimed): the same K frames again through the instrumented traversal -> exact algorithmic bytes ------
     trace_ms, trace_launches, shade_ms = st["trace_ms"], st["trace_launches"], st["shade_ms"]
-    pt.Reset()
-    pt.SetInstrumentation(timing=False, counters=True)
-    if args.warmup:
-        pt.Trace(True, args.warmup)
-    pt.ResetStats()
-    pt.Trace(True, args.steps)
-    cs = pt.GetStats()
-    assert cs["rays"] == st["rays"], "census pass traced a different number of rays"
-    pt.SetInstrumentation(False, False)
-    # per ray 80 B x nodes visited + 48 B x triangles tested + 4 B x hit remap + 32 B ray read + 16 B hit write
-    alg_bytes = 80 * cs["nodes_visited"] + 48 * cs["tris_tested"] + 4 * cs["hits"] + 48 * cs["rays"]
-    achieved = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_trace<false, false>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "launches": int(trace_launches), "avg_launch_ms": round(trace_ms / max(1, trace_launches), 4),
+    cs = census(pt, args.steps, args.warmup, st["rays"])
+    alg_bytes = cs["alg_bytes"]
+    alg_gbs = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+    kernel_rays_s = st["rays"] / (trace_ms * 1e-3) if trace_ms > 0 else 0.0
+    bvh_mb = (len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 52) / 1e6
+    roofline = {"kernel": "k_trace<false, false>", "launches": int(trace_launches), "avg_launch_ms": round(trace_ms / max(1, trace_launches), 4),
+                "trace_kernel_Mrays_s": round(kernel_rays_s / 1e6, 1),
                 "alg_bytes_per_launch": round(alg_bytes / max(1, trace_launches)), "alg_bytes_per_ray": round(alg_bytes / max(1, cs["rays"]), 1),
                 "nodes_per_ray": round(cs["nodes_visited"] / max(1, cs["rays"]), 2), "tris_per_ray": round(cs["tris_tested"] / max(1, cs["rays"]), 2),
-                "trace_kernel_Mrays_s": round(st["rays"] / (trace_ms * 1e3), 1) if trace_ms > 0 else None,
-                "note": "algorithmic bytes / HIP-event time of the traversal launches of rank 0.  The BVH (nodes+Woop %.0f MB) is L2/Infinity-Cache "
-                        "resident, so most algorithmic bytes never reach HBM (see traffic / traffic_GBs) and frac can exceed 1; the kernel is bound "
-                        "by vector-ALU issue (profiles/: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs = its duration)" %
-                        ((len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 48) / 1e6)}
+                "alg_GBs": round(alg_gbs, 1), "alg_frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "hbm_peak_GBs": HBM_PEAK_GBS,
+                "traffic": None}
+    # The PMC counters cannot be read from inside this process: per-ray figures come from the committed rocprofv3 --pmc passes
+    # over this very command line (tools/collect_profiles.sh -> profiles/r2_pmc_bench.json) x the rays / time measured here.
+    pmc = load_profile("r2_pmc_bench.json")
+    use_pmc = pmc if (pmc and world == 1 and (args.scene, args.width, args.height) == ("sponza", 1920, 1080)) else None
+    if use_pmc and "valu_insts_per_ray" in use_pmc:
+        achieved = use_pmc["valu_insts_per_ray"] * kernel_rays_s / 1e9
+        roofline.update({"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINSTR, 1), "unit": "Ginstr/s",
+                         "frac": round(achieved / VALU_PEAK_GINSTR, 4), "lane_util": round(use_pmc["lane_util"], 4),
+                         "useful_frac": round(achieved / VALU_PEAK_GINSTR * use_pmc["lane_util"], 4),
+                         "valu_insts_per_ray": round(use_pmc["valu_insts_per_ray"], 2)})
+    else:
+        roofline.update({"bound": "hbm", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4)})
+    if use_pmc and "traffic_bytes_per_ray" in use_pmc:
+        roofline["traffic"] = round(use_pmc["traffic_bytes_per_ray"] * st["rays"] / max(1, trace_launches))
+        roofline["traffic_GBs"] = round(use_pmc["traffic_bytes_per_ray"] * kernel_rays_s / 1e9, 1)
+        roofline["traffic_frac_of_hbm_peak"] = round(use_pmc["traffic_bytes_per_ray"] * kernel_rays_s / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["l2_hit_rate"] = round(use_pmc.get("TCC_hit_rate", 0.0), 3)
+    roofline["note"] = ("BVH (nodes + Woop + index) %.0f MB is L2 / Infinity-Cache resident: most algorithmic bytes never reach HBM (traffic << "
+                        "alg_bytes_per_launch, no re-reads wasted) and alg_frac_of_hbm_peak may exceed 1 — the HBM roof does not bind on this scene "
+                        "(it does on roofline_hbm_resident).  What binds is vector-ALU issue: achieved = PMC SQ_INSTS_VALU per ray (%s) x the "
+                        "kernel's measured rays/s, peak = 1024 SIMDs x 1 wave-instruction / 4 cycles x 2.4 GHz; lane_util = "
+                        "SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)" % (bvh_mb, (use_pmc or {}).get("command", "no committed PMC file for this configuration")))
 
-    # `traffic`: HBM/fabric bytes per launch of the same kernel from the PMC counters (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024,
-    # gfx950 corrections of MI355X_MICROARCH.md).  Counters cannot be read from inside this process; the value comes
-    # from the committed rocprofv3 --pmc passes over this very command (tools/collect_profiles.sh -> profiles/r1_pmc_traffic.json).
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        if world == 1 and (args.scene, args.width, args.height) == ("sponza", 1920, 1080):
-            roofline["traffic"] = round(pmc["traffic_bytes_per_ray"] * st["rays"] / max(1, trace_launches))
-            # the same traffic as a rate: what the fabric (Infinity Cache + HBM) actually delivered while the kernel ran
-            roofline["traffic_GBs"] = round(pmc["traffic_bytes_per_ray"] * st["rays"] / (trace_ms * 1e-3) / 1e9, 1) if trace_ms > 0 else None
-            roofline["traffic_source"] = ("profiles/r1_pmc_traffic.json: %.1f fabric bytes per ray (separate rocprofv3 --pmc passes of bench.py --steps 64 --warmup 0) "
-                                          "x the rays per launch of this run; L2 hit rate %.2f" % (pmc["traffic_bytes_per_ray"], pmc["TCC_hit_rate"]))
-    except (OSError, KeyError, ValueError):
-        pass
+    # ---- one frame per call (Instance::Update -> Trace(true), src/Instance.cpp:44-57) with the library's look-ahead ----------
+    single = None
+    if world == 1 and not args.no_single_frame:
+        n_calls = 64
+        pt.Reset()
+        pt.SetInstrumentation(False, False)
+        pt.SetLookahead(True)
+        for _ in range(pt.GetFramesInFlight()):
+            pt.Trace(True, 1)  # warm-up: one whole pass handed out
+        pt.ResetStats()
+        pt.DeviceSynchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_calls):
+            pt.Trace(True, 1)
+        pt.DeviceSynchronize()
+        dt = time.perf_counter() - t1
+        s1 = pt.GetStats()
+        pt.SetLookahead(False)
+        pt.SetFramesInFlight(1)  # and without look-ahead, one frame per wavefront pass: what round 1's binding did
+        pt.Reset()
+        pt.Trace(True, 16)
+        pt.ResetStats()
+        t1 = time.perf_counter()
+        pt.Trace(True, 16)
+        dt0 = time.perf_counter() - t1
+        s0 = pt.GetStats()
+        single = {"calls": n_calls, "ms_per_call": round(dt * 1e3 / n_calls, 4), "Mrays_s": round(s1["rays"] / dt / 1e6, 1),
+                  "frac_of_batched": round((s1["rays"] / dt) / (total_rays / elapsed), 3),
+                  "without_lookahead_Mrays_s": round(s0["rays"] / dt0 / 1e6, 1),
+                  "note": "adypt_trace_spp(ctx, 1) per call, adypt_set_lookahead on: a call that needs untraced frames traces a whole pass of %d, the following calls only apply their running-mean step" % fif}
 
-    # ---- CPU baseline: the oracle's scalar traversal + shading of the same workload, bounded sample ---------------------
+    # ---- the kernel where HBM binds, and the CPU baseline ----------------------------------------------------------------------
+    hbm = None
+    if rank == 0 and world == 1 and not args.no_hbm_block and args.scene == "sponza":
+        pt.destroy()  # frees the bench scene's queues first
+        hbm = hbm_resident_block(args, dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle_py as O
-        osc = O.Scene(inst.bvh.nodes, inst.bvh.tri_indices, inst.scene.triangles, inst.scene.materials, textures=inst.scene.textures)
-        ip, iv = O.camera(c.fov, c.yaw, c.pitch, c.width, c.height)
-        P = O.make_params(c.width, c.height, list(c.position), ip, iv, stack_size=c.stack_size, max_bounce=c.max_bounce, subpixel=c.subpixel,
-                          tmp_life=1, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))
-        sm = np.fromfile(os.path.join(ROOT, "tests", "golden", "sobol_matrices_64x32.u32"), dtype=np.uint32).reshape(64, 32)
-        cores = O.default_threads()
-        stc = O.PathTracerState(c.width, c.height)
-        shift = O.shift_bytes(12345, c.width, c.height)
-        cpu_rays, cpu_t, frames = 0, 0.0, 0
-        while cpu_t < 10.0 and frames < 16:
-            t1 = time.perf_counter()
-            s = O.pt_frames(osc, P, shift, sm, stc, 1, n_threads=cores)
-            cpu_t += time.perf_counter() - t1
-            cpu_rays += s.rays
-            frames += 1
-        # one thread (SURVEY.md §8d asks for both): a quarter-height frame keeps it to a few seconds
-        P1 = O.make_params(c.width, c.height // 4, list(c.position), *O.camera(c.fov, c.yaw, c.pitch, c.width, c.height // 4), stack_size=c.stack_size,
-                           max_bounce=c.max_bounce, subpixel=c.subpixel, tmp_life=1, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))
-        st1 = O.PathTracerState(c.width, c.height // 4)
-        t1 = time.perf_counter()
-        s1 = O.pt_frames(osc, P1, O.shift_bytes(12345, c.width, c.height // 4), sm, st1, 1, n_threads=1)
-        t1 = time.perf_counter() - t1
-        cpu = {"value": round(cpu_rays / cpu_t / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-               "sample": "%d full %dx%d frames (every frame traces its primaries), %d rays, %.1f s, oracle/liboracle.so on %d threads"
-                         % (frames, c.width, c.height, cpu_rays, cpu_t, cores),
-               "value_1_thread": round(s1.rays / t1 / 1e6, 3),
-               "sample_1_thread": "one %dx%d frame, %d rays, %.1f s" % (c.width, c.height // 4, s1.rays, t1)}
+        cpu = cpu_baseline(inst, c)
 
     if rank == 0:
         value = total_rays / elapsed / 1e6
@@ -203,15 +343,19 @@ def main() -> None:
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s-like procedural stand-in (%s), %d triangles, %dx%d, full wavefront path trace, maxBounce %d, tmpLifetime %d, 1 spp per step; one radiance gather per run"
                                       % (args.scene, spec.label, inst.scene.n_tris, c.width, c.height, c.max_bounce, c.tmp_lifetime),
-                          "rays_per_step": round(total_rays / max(1, args.steps)), "tile_shard": "32x32 blocks, owner (bx+by) mod N", "frames_in_flight": pt.GetFramesInFlight(), "setup_s": round(t_setup, 2)},
-               "roofline": roofline, "cpu_baseline": cpu,
+                          "rays_per_step": round(total_rays / max(1, args.steps)), "tile_shard": "32x32 blocks, owner (bx+by) mod N",
+                          "frames_in_flight": fif, "rays_warmup": rays_warmup, "comm": ("torch.distributed" if use_torch else "native RCCL") if world > 1 else "none",
+                          "setup_s": round(t_setup, 2)},
+               "roofline": roofline, "roofline_hbm_resident": hbm, "cpu_baseline": cpu, "single_frame": single,
                "gather_ms": round(gather_ms, 3), "shade_kernels_ms": round(shade_ms, 2), "trace_kernels_ms": round(trace_ms, 2),
                "image_mean": float(image.mean()) if image is not None else None}
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_torch:
         dist.barrier()
         dist.destroy_process_group()
+    elif world > 1:
+        pt.CommBarrier()
 
 
 if __name__ == "__main__":

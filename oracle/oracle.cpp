@@ -495,6 +495,73 @@ static bool fetch_info(const OrcScene &sc, int tri_idx, float u, float v, Surfac
 	return true;
 }
 
+// The material response of one loop iteration of Render (pathtracer.glsl:141-201): normal flip, `illum` switch, new direction
+// and throughput.  Returns false where the GLSL has `return ret` (glossy sample below the surface, :151).  A separate function
+// only so that tests can drive it with hand-made surfaces (orc_scatter); render() below is its one caller.
+static bool scatter_step(const Surface &s, const PixelRng &rng, int b, V3 &dir, V3 &color, float *fresnel_out)
+{
+	const Mat &m = *s.mtl;
+	V3 normal = s.normal;
+	if(m.illum < 6 && dot3(dir, normal) > 0) normal = -normal;
+
+	int illum = m.illum;
+	if(illum == 2)
+	{
+		float e = m.shininess * 0.01f;
+		if(e > 0.3f)
+		{
+			V3 r = reflect3(dir, normal), sh = sample_hemisphere(rng, b, e);
+			dir = align_direction(sh, r);
+			if(dot3(dir, normal) < 0.0f) return false;
+			float pw = canon_pow(dot3(dir, r), e);
+			color = color * fma3(s.specular, pw, s.diffuse);
+			return true;
+		}
+		illum = 1; // falls through to diffuse
+	}
+	if(illum == 1)
+	{
+		dir = align_direction(sample_hemisphere(rng, b, 0.0f), normal);
+		color = color * s.diffuse;
+	}
+	else if(illum >= 3 && illum <= 5)
+	{
+		color = color * s.specular;
+		dir = reflect3(dir, normal);
+	}
+	else if(illum == 6 || illum == 7)
+	{
+		float eta = m.ior;
+		float cosi = dot3(dir, normal);
+		float fresnel, etai, etat;
+		if(cosi > 0) { etai = eta; etat = 1.0f; }
+		else { etai = 1.0f; etat = eta; normal = -normal; cosi = -cosi; }
+		eta = etai / etat;
+		float sint = (etai / etat) * sqrtf(gl_max(0.0f, fmaf(-cosi, cosi, 1.0f)));
+		if(sint >= 1.0f) fresnel = 1.0f;
+		else
+		{
+			float cost = sqrtf(gl_max(0.0f, fmaf(-sint, sint, 1.0f)));
+			float A = etat * cosi, B = etai * cost, C = etai * cosi, D = etat * cost;
+			float Rs = (A - B) / (A + B);
+			float Rp = (C - D) / (C + D);
+			fresnel = fmaf(Rs, Rs, Rp * Rp) * 0.5f;
+		}
+		if(fresnel_out) *fresnel_out = fresnel;
+		float cos2 = fmaf(-(eta * eta), fmaf(-cosi, cosi, 1.0f), 1.0f);
+		float sx, sy; sobol2(rng, b, &sx, &sy);
+		if(cos2 > 0 && sx >= fresnel)
+		{
+			float k = fmaf(eta, cosi, sqrtf(cos2));
+			dir = normalize3(fma3(normal, k, dir * eta));
+		}
+		else
+			dir = reflect3(dir, normal);
+	}
+	// any other illum: the ray continues straight through (no case in the reference's switch)
+	return true;
+}
+
 // Render: pathtracer.glsl:101-204.  cache = this pixel's {tri_idx, u, v} slot of uPrimaryTmpImg.
 static V3 render(const OrcScene &sc, const OrcParams &p, int spp, V3 dir, const PixelRng &rng, int32_t *cache_tri,
 				 float *cache_uv, Counters &cn)
@@ -538,64 +605,7 @@ static V3 render(const OrcScene &sc, const OrcParams &p, int spp, V3 dir, const 
 		++cn.shaded;
 		o4[0] = s.position.x; o4[1] = s.position.y; o4[2] = s.position.z;
 		ret = fma3(color, s.emissive, ret);
-		const Mat &m = *s.mtl;
-		V3 normal = s.normal;
-		if(m.illum < 6 && dot3(dir, normal) > 0) normal = -normal;
-
-		int illum = m.illum;
-		if(illum == 2)
-		{
-			float e = m.shininess * 0.01f;
-			if(e > 0.3f)
-			{
-				V3 r = reflect3(dir, normal), sh = sample_hemisphere(rng, b, e);
-				dir = align_direction(sh, r);
-				if(dot3(dir, normal) < 0.0f) return ret;
-				float pw = canon_pow(dot3(dir, r), e);
-				color = color * fma3(s.specular, pw, s.diffuse);
-				continue;
-			}
-			illum = 1; // falls through to diffuse
-		}
-		if(illum == 1)
-		{
-			dir = align_direction(sample_hemisphere(rng, b, 0.0f), normal);
-			color = color * s.diffuse;
-		}
-		else if(illum >= 3 && illum <= 5)
-		{
-			color = color * s.specular;
-			dir = reflect3(dir, normal);
-		}
-		else if(illum == 6 || illum == 7)
-		{
-			float eta = m.ior;
-			float cosi = dot3(dir, normal);
-			float fresnel, etai, etat;
-			if(cosi > 0) { etai = eta; etat = 1.0f; }
-			else { etai = 1.0f; etat = eta; normal = -normal; cosi = -cosi; }
-			eta = etai / etat;
-			float sint = (etai / etat) * sqrtf(gl_max(0.0f, fmaf(-cosi, cosi, 1.0f)));
-			if(sint >= 1.0f) fresnel = 1.0f;
-			else
-			{
-				float cost = sqrtf(gl_max(0.0f, fmaf(-sint, sint, 1.0f)));
-				float A = etat * cosi, B = etai * cost, C = etai * cosi, D = etat * cost;
-				float Rs = (A - B) / (A + B);
-				float Rp = (C - D) / (C + D);
-				fresnel = fmaf(Rs, Rs, Rp * Rp) * 0.5f;
-			}
-			float cos2 = fmaf(-(eta * eta), fmaf(-cosi, cosi, 1.0f), 1.0f);
-			float sx, sy; sobol2(rng, b, &sx, &sy);
-			if(cos2 > 0 && sx >= fresnel)
-			{
-				float k = fmaf(eta, cosi, sqrtf(cos2));
-				dir = normalize3(fma3(normal, k, dir * eta));
-			}
-			else
-				dir = reflect3(dir, normal);
-		}
-		// any other illum: the ray continues straight through (no case in the reference's switch)
+		if(!scatter_step(s, rng, b, dir, color, nullptr)) return ret;
 	}
 	return ret;
 }
@@ -933,4 +943,49 @@ ORC_API void orc_brute_force(const void *triangles, int64_t n_tris, const float 
 	});
 }
 
-ORC_API int orc_abi_version(void) { return 1; }
+
+// ---- test hooks: the shading pieces on their own (tests/test_oracle_shading.py checks them against fp64 closed forms) --------
+// SampleHemisphere (pathtracer.glsl:52-64) for n (r.x, r.y) pairs in [0,1): the pairs are used as Sobol(b) directly (shift 0)
+ORC_API void orc_sample_hemisphere(const float *r, int n, float e, float *out)
+{
+	for(int i = 0; i < n; ++i)
+	{
+		PixelRng rng{0.0f, 0.0f, r + (size_t)i * 2};
+		V3 d = sample_hemisphere(rng, 0, e);
+		out[i * 3] = d.x; out[i * 3 + 1] = d.y; out[i * 3 + 2] = d.z;
+	}
+}
+// AlignDirection (pathtracer.glsl:66-71)
+ORC_API void orc_align_direction(const float *dir, const float *target, int n, float *out)
+{
+	for(int i = 0; i < n; ++i)
+	{
+		V3 r = align_direction(v3(dir[i * 3], dir[i * 3 + 1], dir[i * 3 + 2]), v3(target[i * 3], target[i * 3 + 1], target[i * 3 + 2]));
+		out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z;
+	}
+}
+// one material response (pathtracer.glsl:141-201) per record: material (64 B), unit normal, incoming direction, Sobol point of
+// the bounce (2 floats, shift 0); diffuse / specular are the material's Kd / Ks.  out per record: new direction (3), throughput
+// factor (3), Fresnel term (dielectrics, else -1), alive (1 / 0).
+ORC_API void orc_scatter(const void *materials, const float *normal, const float *dir_in, const float *r, int n, float *out)
+{
+	const Mat *mats = (const Mat *)materials;
+	for(int i = 0; i < n; ++i)
+	{
+		Surface s;
+		s.mtl = &mats[i];
+		s.normal = v3(normal[i * 3], normal[i * 3 + 1], normal[i * 3 + 2]);
+		s.position = v3(0, 0, 0);
+		s.emissive = v3(mats[i].er, mats[i].eg, mats[i].eb);
+		s.diffuse = v3(mats[i].dr, mats[i].dg, mats[i].db);
+		s.specular = v3(mats[i].sr, mats[i].sg, mats[i].sb);
+		PixelRng rng{0.0f, 0.0f, r + (size_t)i * 2};
+		V3 dir = v3(dir_in[i * 3], dir_in[i * 3 + 1], dir_in[i * 3 + 2]), color = v3(1, 1, 1);
+		float fresnel = -1.0f;
+		const bool alive = scatter_step(s, rng, 0, dir, color, &fresnel);
+		float *o = out + (size_t)i * 8;
+		o[0] = dir.x; o[1] = dir.y; o[2] = dir.z; o[3] = color.x; o[4] = color.y; o[5] = color.z; o[6] = fresnel; o[7] = alive ? 1.0f : 0.0f;
+	}
+}
+
+ORC_API int orc_abi_version(void) { return 2; }

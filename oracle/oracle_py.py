@@ -71,7 +71,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_abi_version.restype = C.c_int
-        assert _lib.orc_abi_version() == 1
+        assert _lib.orc_abi_version() == 2
     return _lib
 
 
@@ -250,6 +250,37 @@ def pt_frames(scene: Scene, params: _Params, shift: np.ndarray, sobol_matrices: 
                         C.c_int(n_threads or default_threads()))
     state.spp += n_spp
     return st
+
+
+def sample_hemisphere(r: np.ndarray, e: float) -> np.ndarray:
+    """SampleHemisphere (pathtracer.glsl:52-64) for (r.x, r.y) pairs in [0,1) — test hook."""
+    r = np.ascontiguousarray(r, dtype=np.float32).reshape(-1, 2)
+    out = np.empty((len(r), 3), dtype=np.float32)
+    lib().orc_sample_hemisphere(_p(r), C.c_int(len(r)), C.c_float(e), _p(out))
+    return out
+
+
+def align_direction(direction: np.ndarray, target: np.ndarray) -> np.ndarray:
+    """AlignDirection (pathtracer.glsl:66-71) — test hook."""
+    d = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(target, dtype=np.float32).reshape(-1, 3)
+    out = np.empty_like(d)
+    lib().orc_align_direction(_p(d), _p(t), C.c_int(len(d)), _p(out))
+    return out
+
+
+def scatter(materials: np.ndarray, normal: np.ndarray, dir_in: np.ndarray, r: np.ndarray) -> np.ndarray:
+    """One material response (pathtracer.glsl:141-201) per record — test hook.  Returns n x 8: new direction, throughput factor,
+    Fresnel term (-1 unless dielectric), alive."""
+    m = np.ascontiguousarray(materials)
+    assert m.dtype == MAT_DT
+    nrm = np.ascontiguousarray(normal, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(dir_in, dtype=np.float32).reshape(-1, 3)
+    rr = np.ascontiguousarray(r, dtype=np.float32).reshape(-1, 2)
+    assert len(m) == len(nrm) == len(d) == len(rr)
+    out = np.empty((len(m), 8), dtype=np.float32)
+    lib().orc_scatter(_p(m), _p(nrm), _p(d), _p(rr), C.c_int(len(m)), _p(out))
+    return out
 
 
 def brute_force(triangles: np.ndarray, rays: np.ndarray, n_threads: Optional[int] = None):
