@@ -330,7 +330,7 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 
 // One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for every live path.
 // store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
-__global__ __launch_bounds__(kShadeThreads, 6) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, ShadowArgs sh, int b, int store_cache, int count_stats)
+__global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, ShadowArgs sh, int b, int store_cache, int count_stats)
 {
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	const uint32_t n_in = q.count_in[seg * kCursorStride];
