@@ -145,6 +145,7 @@ _SIGS = {
     "adypt_scene_materials": (C.c_int64, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "adypt_scene_textures": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "adypt_scene_aabb": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "adypt_scene_warnings": (C.c_char_p, [C.c_void_p]),
     "adypt_scene_from_arrays": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "adypt_host_set_threads": (C.c_int, [C.c_int]),
     "adypt_host_get_threads": (C.c_int, []),

@@ -90,6 +90,7 @@ class Scene:
         self.triangles = np.zeros(0, dtype=np.uint8)
         self.materials = np.zeros(0, dtype=np.uint8)
         self.textures: List[np.ndarray] = []
+        self.warnings = ""
 
     def LoadFromFile(self, filename: str) -> bool:
         self._free()
@@ -119,6 +120,8 @@ class Scene:
             arr = (N.Texture * nt).from_address(p.value)
             for t in arr:
                 self.textures.append(_bytes_view(t.rgb, t.width * t.height * 3).reshape(t.height, t.width, 3))
+        w = N.lib.adypt_scene_warnings(self._h)
+        self.warnings = (w or b"").decode("utf-8", "replace")  # textures that could not be decoded (their materials render black)
 
     def GetTriangles(self) -> np.ndarray:
         return self.triangles

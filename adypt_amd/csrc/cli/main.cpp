@@ -50,6 +50,7 @@ int main(int argc, char **argv)
 	int64_t n_tris = adypt_scene_triangles(scene, &tris), n_mats = adypt_scene_materials(scene, &mats);
 	int32_t n_tex = adypt_scene_textures(scene, &tex);
 	printf("[SCENE]Info: %lld triangles loaded from %s\n", (long long)n_tris, cfg.obj_filename);
+	if(*adypt_scene_warnings(scene)) printf("[SCENE]Warn: %s", adypt_scene_warnings(scene)); // undecodable textures: their materials render black
 
 	adypt_bvh *bvh = nullptr;
 	if(adypt_bvh_load(cfg.bvh_filename, &cfg.bvh, &bvh) != ADYPT_OK)

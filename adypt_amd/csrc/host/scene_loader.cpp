@@ -277,6 +277,7 @@ struct SceneData {
 	std::vector<adypt_texture> tex_desc;
 	Box box;
 	std::string base_dir;
+	std::string warnings; // one line per texture that could not be decoded (the material then renders as the reference's failed stbi_load: black)
 };
 
 static bool load_obj(const char *path, SceneData *sc, std::string *err)
@@ -411,7 +412,11 @@ static bool load_obj(const char *path, SceneData *sc, std::string *err)
 				}
 				else
 				{
+					// the reference prints and carries on with m_dtex = -1 and Kd = 0 (src/Tracer/OglScene.cpp:12-43,62-66); so does this
+					// loader, but the caller can ask what was lost (adypt_scene_warnings): formats stb_image reads and this decoder
+					// does not (JPEG, interlaced PNG, ...) would otherwise render differently without a trace
 					fprintf(stderr, "[adypt] unable to load texture %s (%s)\n", full.c_str(), ierr.c_str());
+					sc->warnings += "texture " + full + ": " + ierr + " — material '" + m.name + "' renders with Kd = 0\n";
 					g.dtex = -1;
 				}
 			}
@@ -459,6 +464,7 @@ void adypt_scene_free(adypt_scene *s) { delete s; }
 int64_t adypt_scene_triangles(const adypt_scene *s, const void **tris) { if(tris) *tris = s->d.tris.data(); return (int64_t)s->d.tris.size(); }
 int64_t adypt_scene_materials(const adypt_scene *s, const void **mats) { if(mats) *mats = s->d.mats.data(); return (int64_t)s->d.mats.size(); }
 int32_t adypt_scene_textures(const adypt_scene *s, const void **tex) { if(tex) *tex = s->d.tex_desc.data(); return (int32_t)s->d.tex_desc.size(); }
+const char *adypt_scene_warnings(const adypt_scene *s) { return s ? s->d.warnings.c_str() : ""; }
 void adypt_scene_aabb(const adypt_scene *s, float lo[3], float hi[3])
 {
 	for(int k = 0; k < 3; ++k) { lo[k] = s->d.box.lo[k]; hi[k] = s->d.box.hi[k]; }

@@ -55,6 +55,10 @@ int64_t adypt_scene_triangles(const adypt_scene *s, const void **tris);   /* 100
 int64_t adypt_scene_materials(const adypt_scene *s, const void **mats);   /* 64-byte GPUMaterial records */
 int32_t adypt_scene_textures(const adypt_scene *s, const void **tex /* adypt_texture[] */);
 void adypt_scene_aabb(const adypt_scene *s, float lo[3], float hi[3]);
+/* "" or one line per diffuse texture that could not be decoded: like the reference after a failed stbi_load
+ * (src/Tracer/OglScene.cpp:12-43) the scene still loads and the material renders with Kd = 0, but the loss is reported
+ * (this decoder reads PNM, PNG, BMP, TGA; stb_image also reads JPEG, interlaced PNG, GIF, PSD, HDR, PIC) */
+const char *adypt_scene_warnings(const adypt_scene *s);
 /* wrap caller-provided triangles (no OBJ): used for huge procedural scenes */
 int adypt_scene_from_arrays(const void *tris, int64_t n_tris, const void *mats, int64_t n_mats, adypt_scene **out);
 

@@ -255,3 +255,22 @@ def test_texture_decoders(tmp_path):
     assert sc.LoadFromFile(str(tmp_path / "o_bad.obj"))
     m = np.frombuffer(sc.materials.tobytes(), dtype=O.MAT_DT)
     assert m["dtex"][0] == -1 and m["kd"][0].tolist() == [0, 0, 0]  # failed load: dtex -1, Kd left zero (OglScene.cpp:60-68)
+
+
+def test_undecodable_texture_is_reported_not_silent(tmp_path):
+    """A diffuse texture this loader cannot decode (here: a JPEG, which stb_image would read) must not vanish silently: the scene
+    loads like the reference's after a failed stbi_load (m_dtex = -1, Kd = 0, src/Tracer/OglScene.cpp:12-43,62-66) and
+    adypt_scene_warnings names the file and the material."""
+    from adypt_amd import api
+    from oracle import oracle_py as O
+    (tmp_path / "t.obj").write_text("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\nusemtl b\nf 1/1 3/3 2/2\n")
+    (tmp_path / "t.mtl").write_text("newmtl a\nKd 0.5 0.5 0.5\nmap_Kd photo.jpg\nillum 1\nnewmtl b\nKd 0.2 0.3 0.4\nillum 1\n")
+    (tmp_path / "photo.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    sc = api.Scene()
+    assert sc.LoadFromFile(str(tmp_path / "t.obj"))
+    assert "photo.jpg" in sc.warnings and "'a'" in sc.warnings and sc.warnings.count("\n") == 1
+    mats = np.frombuffer(np.ascontiguousarray(sc.materials).tobytes(), dtype=O.MAT_DT)
+    assert mats[0]["dtex"] == -1 and not mats[0]["kd"].any() and len(sc.textures) == 0
+    assert np.allclose(mats[1]["kd"], [0.2, 0.3, 0.4])
+    ok = api.Scene()
+    assert ok.LoadFromFile(os.path.join(os.path.dirname(__file__), "golden", "tiny0.obj")) and ok.warnings == ""

@@ -18,6 +18,7 @@ OUT=gpurun_out/profiles_$TAG; rm -rf $OUT; mkdir -p $OUT
 $CMD > $OUT/plain_run.json 2> /dev/null   # builds the scene cache outside the profiled runs; also the un-profiled reference line
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $FULL > $OUT/stats_bench.json 2> $OUT/stats.err
 cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+python3 tools/kernel_trace_phases.py $OUT/stats $OUT/stats_bench.json > $OUT/kernel_trace_phases.json
 for grp in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
   tag=$(echo $grp | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -- $CMD > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err
