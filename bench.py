@@ -214,6 +214,12 @@ def main() -> None:
     else:
         if world > 1:
             pt.CommInit(D.exchange_unique_id(rank, world))  # the ranks' only exchange outside RCCL: the 128-byte communicator id
+            pt.CommBarrier()
+            if rank == 0:  # every rank holds the communicator now: a later job must never find this id
+                try:
+                    os.remove(D.rendezvous_path())
+                except OSError:
+                    pass
 
         def barrier():
             # every rank's GPU drained (hipDeviceSynchronize), then all ranks met (RCCL all-reduce + drain)
