@@ -15,10 +15,11 @@ radiance on rank 0 (RCCL over xGMI, inside the library: adypt_comm_gather_radian
 
 What the JSON line carries besides the contract's fields:
   roofline               the traversal kernel on the bench scene.  Its BVH (19 MB) is cache resident, so the HBM roof does not
-                         bind; the kernel is bound by vector-ALU issue -> bound "valu_issue", achieved = issued wave-instructions
-                         per second (PMC count per ray x measured rays/s of the kernel) against 1024 SIMDs x 1 instruction / 4
-                         cycles x 2.4 GHz; lane_util = fraction of the 64 lanes doing work in an issued instruction.  The
-                         algorithmic HBM-read figure of SURVEY.md §8(d) and the measured fabric traffic are reported next to it.
+                         bind; the kernel is bound by vector-ALU issue (with the CU's vector-memory pipeline close behind) ->
+                         bound "valu_issue", achieved = vector-ALU issue cycles demanded per second (PMC instructions per ray x
+                         measured rays/s of the kernel x the average issue cycles of its instruction mix) against 1024 SIMDs x
+                         2.4 GHz; lane_util = fraction of the 64 lanes doing work in an issued instruction.  The algorithmic
+                         HBM-read figure of SURVEY.md §8(d) and the measured fabric traffic are reported next to it.
   roofline_hbm_resident  the same kernel on the ~10 M-triangle stand-in of BASELINE config 4 (BVH 0.6 GB > 256 MB Infinity
                          Cache): here HBM binds -> bound "hbm", algorithmic bytes / HIP-event time / 8 TB/s.
   single_frame           one adypt_trace_spp(ctx, 1) per call (what Instance::Update does), with the library's look-ahead.
@@ -40,8 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec)
-VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0  # 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles (16 lanes/clk for fp32 and integer
-                                     # ops; only v_pk_* do two per lane), 2.4 GHz: 614.4 G wave-instructions/s
+VALU_PEAK_GCYCLES = 1024 * 2.4  # 256 CUs x 4 SIMDs x 2.4 GHz: vector-ALU issue cycles per second (a full-rate wave64 instruction takes
+                                # 2 of them, most of this kernel's take 4: profiles/r2_valu_throughput_microbench.txt)
 PT_CFG = {"maxBounce": 8, "subpixel": 8, "clamp": 4.0, "sun": [12.0, 11.0, 10.0], "stackSize": 24}
 SEED = 12345
 
@@ -106,6 +107,15 @@ def hbm_resident_block(args, dev):
         out["traffic_over_algorithmic"] = round(pmc["traffic_bytes_per_ray"] / (cs["alg_bytes"] / cs["rays"]), 3)
         out["traffic_source"] = "profiles/r2_pmc_sanmiguel.json: %.1f fabric bytes per ray (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, separate rocprofv3 --pmc passes of %s) x the rays per launch of this run" % (
             pmc["traffic_bytes_per_ray"], pmc.get("command", "bench.py --scene sanmiguel"))
+        mix = load_profile("r2_k_trace_instruction_mix.json")
+        if mix and "valu_insts_per_ray" in pmc:
+            rays_s = st["rays"] / (st["trace_ms"] * 1e-3)
+            out["valu_issue_frac"] = round(pmc["valu_insts_per_ray"] * rays_s * mix["avg_issue_cycles_per_inst"] / 1e9 / VALU_PEAK_GCYCLES, 4)
+            out["lane_util"] = round(pmc["lane_util"], 4)
+            out["note"] = ("algorithmic bytes (SURVEY.md §8d) / HIP-event time against the HBM peak, as the contract defines it.  The counters show what is "
+                           "behind it: the L2s still catch %.0f %% of the requests (the top of the tree), so the fabric carries %.2f of the algorithmic bytes, and "
+                           "the vector ALUs are busy for valu_issue_frac of the time — on this scene the kernel sits between the two roofs"
+                           % (100 * pmc.get("TCC_hit_rate", 0.0), pmc["traffic_bytes_per_ray"] / (cs["alg_bytes"] / cs["rays"])))
     pt.destroy()
     return out
 
@@ -282,12 +292,19 @@ def main() -> None:
     # over this very command line (tools/collect_profiles.sh -> profiles/r2_pmc_bench.json) x the rays / time measured here.
     pmc = load_profile("r2_pmc_bench.json")
     use_pmc = pmc if (pmc and world == 1 and (args.scene, args.width, args.height) == ("sponza", 1920, 1080)) else None
-    if use_pmc and "valu_insts_per_ray" in use_pmc:
-        achieved = use_pmc["valu_insts_per_ray"] * kernel_rays_s / 1e9
-        roofline.update({"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINSTR, 1), "unit": "Ginstr/s",
-                         "frac": round(achieved / VALU_PEAK_GINSTR, 4), "lane_util": round(use_pmc["lane_util"], 4),
-                         "useful_frac": round(achieved / VALU_PEAK_GINSTR * use_pmc["lane_util"], 4),
-                         "valu_insts_per_ray": round(use_pmc["valu_insts_per_ray"], 2)})
+    mix = load_profile("r2_k_trace_instruction_mix.json")
+    if use_pmc and mix and "valu_insts_per_ray" in use_pmc:
+        # vector-ALU issue cycles demanded per second = instructions per ray (PMC) x rays/s (measured here) x average issue cycles of
+        # this kernel's instruction mix, against 1024 SIMDs x 2.4 GHz
+        inst_rate = use_pmc["valu_insts_per_ray"] * kernel_rays_s
+        achieved = inst_rate * mix["avg_issue_cycles_per_inst"] / 1e9
+        roofline.update({"bound": "valu_issue", "achieved": round(achieved, 1), "peak": VALU_PEAK_GCYCLES, "unit": "Gcycle/s",
+                         "frac": round(achieved / VALU_PEAK_GCYCLES, 4), "lane_util": round(use_pmc["lane_util"], 4),
+                         "useful_frac": round(achieved / VALU_PEAK_GCYCLES * use_pmc["lane_util"], 4),
+                         "valu_insts_per_ray": round(use_pmc["valu_insts_per_ray"], 2), "valu_Ginst_s": round(inst_rate / 1e9, 1),
+                         "avg_issue_cycles_per_inst": mix["avg_issue_cycles_per_inst"]})
+        if "vmem_rd_insts_per_ray" in use_pmc:  # the co-limiter: the CU's one vector-memory pipeline (profiles/r2_ablations_k_trace.txt)
+            roofline["vmem_busy_est"] = round(use_pmc["vmem_rd_insts_per_ray"] * kernel_rays_s * mix["vmem_cycles_per_load_inst"] / (256 * 2.4e9), 3)
     else:
         roofline.update({"bound": "hbm", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4)})
     if use_pmc and "traffic_bytes_per_ray" in use_pmc:
@@ -297,9 +314,11 @@ def main() -> None:
         roofline["l2_hit_rate"] = round(use_pmc.get("TCC_hit_rate", 0.0), 3)
     roofline["note"] = ("BVH (nodes + Woop + index) %.0f MB is L2 / Infinity-Cache resident: most algorithmic bytes never reach HBM (traffic << "
                         "alg_bytes_per_launch, no re-reads wasted) and alg_frac_of_hbm_peak may exceed 1 — the HBM roof does not bind on this scene "
-                        "(it does on roofline_hbm_resident).  What binds is vector-ALU issue: achieved = PMC SQ_INSTS_VALU per ray (%s) x the "
-                        "kernel's measured rays/s, peak = 1024 SIMDs x 1 wave-instruction / 4 cycles x 2.4 GHz; lane_util = "
-                        "SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)" % (bvh_mb, (use_pmc or {}).get("command", "no committed PMC file for this configuration")))
+                        "(it does on roofline_hbm_resident).  What binds: vector-ALU issue, with the CU's vector-memory pipeline close behind "
+                        "(vmem_busy_est; ablations in profiles/r2_ablations_k_trace.txt).  achieved = PMC SQ_INSTS_VALU per ray (%s) x the kernel's "
+                        "measured rays/s x the average issue cycles of its instruction mix (profiles/r2_k_trace_instruction_mix.json), peak = 1024 SIMDs "
+                        "x 2.4 GHz; lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU): the part of every issued instruction that does work"
+                        % (bvh_mb, (use_pmc or {}).get("command", "no committed PMC file for this configuration")))
 
     # ---- one frame per call (Instance::Update -> Trace(true), src/Instance.cpp:44-57) with the library's look-ahead ----------
     single = None

@@ -28,6 +28,7 @@ rays = bench["config"]["rays_per_step"] * bench["steps"] + bench["config"]["rays
 fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
 hit, req = per_kernel("TCC_HIT_sum"), per_kernel("TCC_REQ_sum")
 insts, tcyc = per_kernel("SQ_INSTS_VALU"), per_kernel("SQ_THREAD_CYCLES_VALU")
+vmem = per_kernel("SQ_INSTS_VMEM_RD")
 busy, wcyc, gui = per_kernel("SQ_BUSY_CYCLES"), per_kernel("SQ_WAVE_CYCLES"), per_kernel("GRBM_GUI_ACTIVE")
 traffic = sum(fetch) * 1024 * 2 + sum(write) * 1024
 out = {
@@ -45,6 +46,7 @@ out = {
     "SQ_INSTS_VALU_per_launch": sum(insts) / max(1, len(insts)),
     "valu_insts_per_ray": sum(insts) / max(1, rays),
     "lane_util": sum(tcyc) / max(1.0, 64.0 * sum(insts)),
+    "vmem_rd_insts_per_ray": sum(vmem) / max(1, rays),
     "GRBM_GUI_ACTIVE_per_launch": sum(gui) / max(1, len(gui)),
     "note": "fabric-side bytes (Infinity-Cache hits are counted, MI355X_MICROARCH.md)",
 }
