@@ -162,6 +162,7 @@ _SIGS = {
     "adypt_shift_bytes": (None, [C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "adypt_save_exr": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "adypt_save_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
+    "adypt_load_image_rgb8": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "adypt_load_exr": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "adypt_free": (None, [C.c_void_p]),
 }

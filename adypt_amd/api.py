@@ -236,6 +236,16 @@ def save_png(path: str, rgba8: np.ndarray) -> None:
     N.check_host(N.lib.adypt_save_png(path.encode(), rgba8.ctypes.data, w, h))
 
 
+def load_image_rgb8(path: str) -> np.ndarray:
+    """stbi_load(path, &w, &h, &c, 3) of OglScene::load_texture: H x W x 3 uint8, row 0 = top."""
+    p, w, h = C.c_void_p(), C.c_int32(), C.c_int32()
+    N.check_host(N.lib.adypt_load_image_rgb8(path.encode(), C.byref(p), C.byref(w), C.byref(h)))
+    try:
+        return np.array(_bytes_view(p.value, w.value * h.value * 3).reshape(h.value, w.value, 3))
+    finally:
+        N.lib.adypt_free(p)
+
+
 def load_exr(path: str) -> np.ndarray:
     p = C.c_void_p()
     w = C.c_int()

@@ -68,5 +68,6 @@ struct BinNode { Box box; int32_t tri; int32_t left; };
 
 void set_host_error(const std::string &msg);
 bool decode_image_rgb8(const std::string &path, TextureImage *out, std::string *err);
+bool decode_jpeg(const std::vector<uint8_t> &bytes, TextureImage *out, std::string *err); // jpeg_decoder.cpp: stb_image's pixels
 
 }  // namespace adypt

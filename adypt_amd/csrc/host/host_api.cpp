@@ -593,6 +593,19 @@ int adypt_load_exr(const char *path, float **rgb_out, int *width, int *height)
 	return ADYPT_OK;
 }
 
+int adypt_load_image_rgb8(const char *path, uint8_t **rgb, int32_t *width, int32_t *height)
+{
+	if(!path || !rgb || !width || !height) { set_host_error("adypt_load_image_rgb8: null argument"); return ADYPT_E_INVALID; }
+	adypt::TextureImage img;
+	std::string err;
+	if(!adypt::decode_image_rgb8(path, &img, &err)) { set_host_error(std::string(path) + ": " + err); return ADYPT_E_PARSE; }
+	*rgb = (uint8_t *)malloc(std::max<size_t>(1, img.rgb.size()));
+	if(!*rgb) { set_host_error("out of memory"); return ADYPT_E_OOM; }
+	memcpy(*rgb, img.rgb.data(), img.rgb.size());
+	*width = img.w; *height = img.h;
+	return ADYPT_OK;
+}
+
 void adypt_free(void *p) { free(p); }
 
 }  // extern "C"

@@ -1,8 +1,9 @@
 // Texture file decoding to tightly packed RGB8, rows top to bottom — what stbi_load(filename, &w, &h, &c, 3)
 // hands to glTextureSubImage2D in the reference (src/Tracer/OglScene.cpp:26-34).  Formats: binary PPM/PGM,
 // PNG (8/16-bit, grey / RGB / palette / alpha, non-interlaced; inflate via zlib), BMP (24/32-bit uncompressed),
-// TGA (true-colour / grey, raw or RLE).  JPEG is not supported (reported as an error, material falls back to
-// "texture missing" exactly like a failed stbi_load: dtex = -1, Kd = 0).
+// TGA (true-colour / grey, raw or RLE), JPEG (baseline and progressive, jpeg_decoder.cpp: stb_image's arithmetic).  A file that
+// cannot be decoded is reported (adypt_scene_warnings) and the material falls back to "texture missing" exactly like a failed
+// stbi_load: dtex = -1, Kd = 0.
 #include "common.hpp"
 
 #include <cstdio>
@@ -218,7 +219,7 @@ bool decode_image_rgb8(const std::string &path, TextureImage *out, std::string *
 	if(b[0] == 'P' && (b[1] == '6' || b[1] == '5')) return decode_pnm(b, out, err);
 	if(memcmp(b.data(), "\x89PNG\r\n\x1a\n", 8) == 0) return decode_png(b, out, err);
 	if(b[0] == 'B' && b[1] == 'M') return decode_bmp(b, out, err);
-	if(b[0] == 0xff && b[1] == 0xd8) { *err = "JPEG textures are not supported"; return false; }
+	if(b[0] == 0xff && b[1] == 0xd8) return decode_jpeg(b, out, err);
 	size_t dot = path.find_last_of('.');
 	std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
 	for(char &c : ext) c = (char)tolower(c);

@@ -414,7 +414,7 @@ static bool load_obj(const char *path, SceneData *sc, std::string *err)
 				{
 					// the reference prints and carries on with m_dtex = -1 and Kd = 0 (src/Tracer/OglScene.cpp:12-43,62-66); so does this
 					// loader, but the caller can ask what was lost (adypt_scene_warnings): formats stb_image reads and this decoder
-					// does not (JPEG, interlaced PNG, ...) would otherwise render differently without a trace
+					// does not (interlaced PNG, GIF, PSD, ...) would otherwise render differently without a trace
 					fprintf(stderr, "[adypt] unable to load texture %s (%s)\n", full.c_str(), ierr.c_str());
 					sc->warnings += "texture " + full + ": " + ierr + " — material '" + m.name + "' renders with Kd = 0\n";
 					g.dtex = -1;

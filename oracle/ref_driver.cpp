@@ -20,6 +20,7 @@
 //   camera FOV YAW PITCH W H OUT.f32            inverse(projection)[16], inverse(view)[16] (column-major)
 //   exrsave IN.rgbf32 W H FP16 OUT.exr          tinyexr SaveEXR exactly as OglPathTracer::SaveResult calls it
 //   exrload IN.exr OUT.rgbaf32                  tinyexr LoadEXR -> prints "W H", writes RGBA f32
+//   imgload IN.(jpg|png|...) OUT.rgb8           stbi_load(file, &w, &h, &c, 3) as OglScene::load_texture calls it -> prints "W H", writes RGB8
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,7 @@
 #include "InstanceConfig.hpp"
 #include <glm/gtc/matrix_transform.hpp>
 #include <tinyexr.h>
+#include <stb_image.h> // declarations only: the implementation is compiled with the reference's OglScene.cpp
 
 namespace sobol_data {
 #include "Util/Sobol.inl"
@@ -180,6 +182,16 @@ int main(int argc, char **argv)
 		printf("%d %d\n", w, h);
 		write_file(argv[3], rgba, (size_t)w * h * 16);
 		free(rgba);
+		return 0;
+	}
+	if(cmd == "imgload" && argc == 4)
+	{
+		int w = 0, h = 0, c = 0;
+		unsigned char *px = stbi_load(argv[2], &w, &h, &c, 3);
+		if(!px) { fprintf(stderr, "stbi_load: %s\n", stbi_failure_reason()); return 1; }
+		printf("%d %d\n", w, h);
+		write_file(argv[3], px, (size_t)w * h * 3);
+		stbi_image_free(px);
 		return 0;
 	}
 	fprintf(stderr, "bad command line\n");

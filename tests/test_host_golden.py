@@ -274,3 +274,40 @@ def test_undecodable_texture_is_reported_not_silent(tmp_path):
     assert np.allclose(mats[1]["kd"], [0.2, 0.3, 0.4])
     ok = api.Scene()
     assert ok.LoadFromFile(os.path.join(os.path.dirname(__file__), "golden", "tiny0.obj")) and ok.warnings == ""
+
+
+def _image_fixtures():
+    idx = json.load(open(os.path.join(GOLDEN, "images", "index.json")))
+    return sorted(idx.items())
+
+
+@pytest.mark.parametrize("name,dim", _image_fixtures(), ids=[n for n, _ in _image_fixtures()])
+def test_texture_decoders_return_stb_images_pixels(name, dim):
+    """Diffuse textures feed the radiance directly (pathtracer.glsl:88-96), and decoders differ (inverse DCT, chroma up-sampling filter,
+    colour matrix, 16-to-8-bit reduction): every file format the loader reads must produce the very bytes the reference's stb_image
+    hands to glTextureSubImage2D (src/Tracer/OglScene.cpp:26-34).  Expected pixels: stbi_load(..., 3) of dep/stb_image.h compiled from
+    the reference's source (tests/golden/make_golden_images.py).  JPEG: baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 / 4:1:1 and
+    3x / 4x factors (stb's nearest-neighbour path), odd sizes, restart intervals, grey, CMYK."""
+    img = api.load_image_rgb8(os.path.join(GOLDEN, "images", name))
+    want = np.fromfile(os.path.join(GOLDEN, "images", os.path.splitext(name)[0] + ".rgb8"), dtype=np.uint8).reshape(dim["h"], dim["w"], 3)
+    assert img.shape == want.shape
+    assert np.array_equal(img, want), "%s: %d of %d bytes differ (max %d)" % (name, (img != want).sum(), want.size, np.abs(img.astype(int) - want).max())
+
+
+def test_corrupt_jpegs_fail_cleanly(tmp_path):
+    good = open(os.path.join(GOLDEN, "images", "j420_progressive_restart.jpg"), "rb").read()
+    rs = np.random.RandomState(0)
+    for k in range(200):
+        b = bytearray(good)
+        if k % 3 == 0:
+            b = b[:rs.randint(2, len(b))]                     # truncated
+        else:
+            for _ in range(rs.randint(1, 6)):
+                b[rs.randint(2, len(b))] = rs.randint(0, 256)  # flipped bytes
+        p = tmp_path / ("c%d.jpg" % k)
+        p.write_bytes(bytes(b))
+        try:
+            img = api.load_image_rgb8(str(p))                 # either an error or an image of the declared size: never a crash
+            assert img.ndim == 3 and img.shape[2] == 3
+        except N.AdyptError:
+            pass
