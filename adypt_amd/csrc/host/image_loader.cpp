@@ -1,7 +1,7 @@
 // Texture file decoding to tightly packed RGB8, rows top to bottom — what stbi_load(filename, &w, &h, &c, 3)
 // hands to glTextureSubImage2D in the reference (src/Tracer/OglScene.cpp:26-34).  Formats: binary PPM/PGM,
-// PNG (8/16-bit, grey / RGB / palette / alpha, non-interlaced; inflate via zlib), BMP (24/32-bit uncompressed),
-// TGA (true-colour / grey, raw or RLE), JPEG (baseline and progressive, jpeg_decoder.cpp: stb_image's arithmetic).  A file that
+// PNG (every colour type and bit depth, Adam7 interlace; inflate via zlib), BMP (24 / 32-bit and 4 / 8-bit palettised, uncompressed),
+// TGA (true-colour 15-32 bits / grey / colour-mapped, raw or RLE), JPEG (baseline and progressive, jpeg_decoder.cpp: stb_image's arithmetic).  A file that
 // cannot be decoded is reported (adypt_scene_warnings) and the material falls back to "texture missing" exactly like a failed
 // stbi_load: dtex = -1, Kd = 0.
 #include "common.hpp"
@@ -58,19 +58,41 @@ bool decode_pnm(const std::vector<uint8_t> &b, TextureImage *out, std::string *e
 	return true;
 }
 
+// BMP as stb_image reads it (dep/stb_image.h:4960-5230), uncompressed: 24 / 32 bits (BGR[A]) and 4 / 8-bit palettised (palette of
+// BGR triples for the 12-byte core header, BGRX quads otherwise; 1-bit files are rejected, as stb_image rejects them); rows bottom-up unless the height is negative.
+// 16-bit and bit-field BMPs are reported as unsupported.
 bool decode_bmp(const std::vector<uint8_t> &b, TextureImage *out, std::string *err)
 {
 	auto u32 = [&](size_t o) { return (uint32_t)b[o] | (uint32_t)b[o + 1] << 8 | (uint32_t)b[o + 2] << 16 | (uint32_t)b[o + 3] << 24; };
 	auto u16 = [&](size_t o) { return (uint32_t)b[o] | (uint32_t)b[o + 1] << 8; };
-	if(b.size() < 54) { *err = "short BMP"; return false; }
-	uint32_t off = u32(10);
-	int32_t w = (int32_t)u32(18), h = (int32_t)u32(22);
-	uint32_t bpp = u16(28), comp = u32(30);
-	if((bpp != 24 && bpp != 32) || (comp != 0 && comp != 3)) { *err = "unsupported BMP variant"; return false; }
-	bool flip = h > 0;
+	if(b.size() < 30) { *err = "short BMP"; return false; }
+	const uint32_t off = u32(10), hsz = u32(14);
+	int32_t w, h;
+	uint32_t bpp, comp = 0;
+	if(hsz == 12) { w = (int32_t)u16(18); h = (int32_t)u16(20); bpp = u16(24); }
+	else
+	{
+		if(b.size() < 54 || !(hsz == 40 || hsz == 56 || hsz == 108 || hsz == 124)) { *err = "unsupported BMP header"; return false; }
+		w = (int32_t)u32(18); h = (int32_t)u32(22); bpp = u16(28); comp = u32(30);
+	}
+	if(bpp == 1) { *err = "monochrome BMP (stb_image rejects it too)"; return false; }
+	const bool paletted = bpp == 4 || bpp == 8;
+	if(!(paletted || bpp == 24 || bpp == 32) || !(comp == 0 || (comp == 3 && bpp == 32))) { *err = "unsupported BMP variant"; return false; }
+	const bool flip = h > 0;
 	if(h < 0) h = -h;
-	size_t stride = (((size_t)w * bpp / 8) + 3) & ~(size_t)3;
-	if(w <= 0 || off + stride * (size_t)h > b.size()) { *err = "truncated BMP"; return false; }
+	if(w <= 0 || h <= 0) { *err = "bad BMP size"; return false; }
+	std::vector<uint8_t> palette;
+	if(paletted)
+	{
+		const size_t eb = hsz == 12 ? 3 : 4, first = 14 + (size_t)hsz;
+		if(off < first || off > b.size()) { *err = "bad BMP palette"; return false; }
+		const size_t n = std::min<size_t>((off - first) / eb, 256);
+		if(n == 0) { *err = "bad BMP palette"; return false; }
+		palette.assign(256 * 3, 0);
+		for(size_t i = 0; i < n; ++i) { palette[i * 3] = b[first + i * eb + 2]; palette[i * 3 + 1] = b[first + i * eb + 1]; palette[i * 3 + 2] = b[first + i * eb]; }
+	}
+	const size_t stride = ((((size_t)w * bpp + 7) / 8) + 3) & ~(size_t)3;
+	if((size_t)off + stride * (size_t)h > b.size()) { *err = "truncated BMP"; return false; }
 	out->w = w; out->h = h;
 	out->rgb.resize((size_t)w * h * 3);
 	for(int y = 0; y < h; ++y)
@@ -78,25 +100,61 @@ bool decode_bmp(const std::vector<uint8_t> &b, TextureImage *out, std::string *e
 		const uint8_t *row = b.data() + off + stride * (size_t)(flip ? h - 1 - y : y);
 		for(int x = 0; x < w; ++x)
 		{
-			const uint8_t *p = row + (size_t)x * (bpp / 8);
 			uint8_t *o = &out->rgb[((size_t)y * w + x) * 3];
-			o[0] = p[2]; o[1] = p[1]; o[2] = p[0];
+			if(paletted)
+			{
+				const size_t bit = (size_t)x * bpp;
+				const unsigned idx = (row[bit >> 3] >> (8 - bpp - (bit & 7))) & ((1u << bpp) - 1u);
+				memcpy(o, &palette[(size_t)idx * 3], 3);
+			}
+			else
+			{
+				const uint8_t *p = row + (size_t)x * (bpp / 8);
+				o[0] = p[2]; o[1] = p[1]; o[2] = p[0];
+			}
 		}
 	}
 	return true;
 }
 
+// TGA as stb_image reads it (dep/stb_image.h:5240-5510): true-colour 24 / 32 bits (BGR[A]) and 15 / 16 bits (5-5-5, each field
+// scaled (v * 255) / 31), grey 8 bits and 16 bits (grey + alpha), colour-mapped with 8- or 16-bit indices (an index past the palette
+// reads entry 0), each raw or run-length encoded; rows bottom-up unless descriptor bit 5 is set; alpha dropped.
 bool decode_tga(const std::vector<uint8_t> &b, TextureImage *out, std::string *err)
 {
 	if(b.size() < 18) { *err = "short TGA"; return false; }
-	int idlen = b[0], cmap = b[1], type = b[2];
-	int w = b[12] | b[13] << 8, h = b[14] | b[15] << 8, bpp = b[16], desc = b[17];
-	if(cmap != 0 || !(type == 2 || type == 3 || type == 10 || type == 11) || !(bpp == 8 || bpp == 24 || bpp == 32))
+	const int idlen = b[0], cmap = b[1], type = b[2];
+	const int pal_start = b[3] | b[4] << 8, pal_len = b[5] | b[6] << 8, pal_bits = b[7];
+	const int w = b[12] | b[13] << 8, h = b[14] | b[15] << 8, bpp = b[16], desc = b[17];
+	const bool rle = type >= 8, indexed = (type & 7) == 1, grey = (type & 7) == 3;
+	if(!((type & 7) >= 1 && (type & 7) <= 3) || type > 11 || w <= 0 || h <= 0) { *err = "unsupported TGA type"; return false; }
+	if(indexed ? !(cmap == 1 && (bpp == 8 || bpp == 16) && (pal_bits == 15 || pal_bits == 16 || pal_bits == 24 || pal_bits == 32))
+			   : !(cmap == 0 && (grey ? (bpp == 8 || bpp == 16) : (bpp == 15 || bpp == 16 || bpp == 24 || bpp == 32))))
 	{ *err = "unsupported TGA variant"; return false; }
 	size_t pos = 18 + (size_t)idlen;
-	int bytes = bpp / 8;
+	// one decoded colour = RGB from a little-endian source pixel of `bits` bits
+	auto to_rgb = [](const uint8_t *p, int bits, bool is_grey, uint8_t *o) {
+		if(is_grey) { o[0] = o[1] = o[2] = p[0]; }
+		else if(bits == 15 || bits == 16)
+		{
+			const unsigned px = p[0] | p[1] << 8;
+			o[0] = (uint8_t)((((px >> 10) & 31) * 255) / 31); o[1] = (uint8_t)((((px >> 5) & 31) * 255) / 31); o[2] = (uint8_t)(((px & 31) * 255) / 31);
+		}
+		else { o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; }
+	};
+	std::vector<uint8_t> palette; // RGB triples
+	if(indexed)
+	{
+		const size_t eb = (size_t)(pal_bits + 7) / 8;
+		pos += (size_t)pal_start * eb; // stb skips `palette start` entries' worth of bytes before the table
+		if(pal_len == 0 || pos + (size_t)pal_len * eb > b.size()) { *err = "truncated TGA palette"; return false; }
+		palette.resize((size_t)pal_len * 3);
+		for(int i = 0; i < pal_len; ++i) to_rgb(&b[pos + (size_t)i * eb], pal_bits, false, &palette[(size_t)i * 3]);
+		pos += (size_t)pal_len * eb;
+	}
+	const int bytes = (bpp + 7) / 8;
 	std::vector<uint8_t> px((size_t)w * h * bytes);
-	if(type == 2 || type == 3)
+	if(!rle)
 	{
 		if(pos + px.size() > b.size()) { *err = "truncated TGA"; return false; }
 		memcpy(px.data(), b.data() + pos, px.size());
@@ -107,7 +165,7 @@ bool decode_tga(const std::vector<uint8_t> &b, TextureImage *out, std::string *e
 		while(o < px.size())
 		{
 			if(pos >= b.size()) { *err = "truncated TGA"; return false; }
-			int hdr = b[pos++], cnt = (hdr & 0x7f) + 1;
+			const int hdr = b[pos++], cnt = (hdr & 0x7f) + 1;
 			if(hdr & 0x80)
 			{
 				if(pos + bytes > b.size()) { *err = "truncated TGA"; return false; }
@@ -116,14 +174,14 @@ bool decode_tga(const std::vector<uint8_t> &b, TextureImage *out, std::string *e
 			}
 			else
 			{
-				size_t nb = (size_t)cnt * bytes;
-				if(pos + nb > b.size() || o + nb > px.size()) { *err = "truncated TGA"; return false; }
+				const size_t nb = std::min((size_t)cnt * bytes, px.size() - o);
+				if(pos + nb > b.size()) { *err = "truncated TGA"; return false; }
 				memcpy(&px[o], &b[pos], nb);
 				pos += nb; o += nb;
 			}
 		}
 	}
-	bool top_origin = (desc & 0x20) != 0;
+	const bool top_origin = (desc & 0x20) != 0;
 	out->w = w; out->h = h;
 	out->rgb.resize((size_t)w * h * 3);
 	for(int y = 0; y < h; ++y)
@@ -131,12 +189,20 @@ bool decode_tga(const std::vector<uint8_t> &b, TextureImage *out, std::string *e
 		{
 			const uint8_t *p = &px[((size_t)(top_origin ? y : h - 1 - y) * w + x) * bytes];
 			uint8_t *o = &out->rgb[((size_t)y * w + x) * 3];
-			if(bytes == 1) o[0] = o[1] = o[2] = p[0];
-			else { o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; }
+			if(indexed)
+			{
+				size_t idx = bytes == 1 ? p[0] : (size_t)(p[0] | p[1] << 8);
+				if(idx >= (size_t)pal_len) idx = 0;
+				memcpy(o, &palette[idx * 3], 3);
+			}
+			else to_rgb(p, bpp, grey, o);
 		}
 	return true;
 }
 
+// PNG as stb_image reduces it to 8-bit RGB (dep/stb_image.h:4260-4560, 4680-4830): every colour type and bit depth, Adam7 interlace;
+// grey samples of 1 / 2 / 4 bits are scaled to 0..255 (x 255 / 85 / 17), palette indices are not; 16-bit samples keep their high byte;
+// alpha (channel or tRNS) is dropped, not blended.
 bool decode_png(const std::vector<uint8_t> &b, TextureImage *out, std::string *err)
 {
 	auto be32 = [&](size_t o) { return (uint32_t)b[o] << 24 | (uint32_t)b[o + 1] << 16 | (uint32_t)b[o + 2] << 8 | (uint32_t)b[o + 3]; };
@@ -159,53 +225,84 @@ bool decode_png(const std::vector<uint8_t> &b, TextureImage *out, std::string *e
 		else if(memcmp(tag, "IEND", 4) == 0) break;
 		pos += 12 + (size_t)len;
 	}
-	if(w == 0 || h == 0 || interlace != 0 || !(depth == 8 || depth == 16 || (ctype == 3 && depth <= 8)))
-	{ *err = "unsupported PNG variant (interlaced or sub-byte depth)"; return false; }
-	int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
-	if(ctype == 3 && depth != 8) { *err = "unsupported PNG palette depth"; return false; }
-	size_t bpp = (size_t)ch * depth / 8, stride = (size_t)w * bpp;
-	std::vector<uint8_t> raw((stride + 1) * h);
-	uLongf rawlen = (uLongf)raw.size();
-	if(uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size())
-	{ *err = "PNG inflate failed"; return false; }
-	std::vector<uint8_t> img(stride * h);
-	for(uint32_t y = 0; y < h; ++y)
+	const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
+						  (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+						  ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+	if(w == 0 || h == 0 || interlace > 1 || !depth_ok || (uint64_t)w * h > ((uint64_t)1 << 28)) { *err = "bad or unsupported PNG header"; return false; }
+	const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
+	const size_t bits_px = (size_t)ch * depth, bpp = std::max<size_t>(1, bits_px / 8); // filter distance in bytes
+	// pass geometry: one pass, or the seven of Adam7
+	static const int xo[7] = {0, 4, 0, 2, 0, 1, 0}, yo[7] = {0, 0, 4, 0, 2, 0, 1}, xs[7] = {8, 8, 4, 4, 2, 2, 1}, ys[7] = {8, 8, 8, 4, 4, 2, 2};
+	const int n_pass = interlace ? 7 : 1;
+	size_t raw_size = 0;
+	for(int p = 0; p < n_pass; ++p)
 	{
-		const uint8_t *src = &raw[(stride + 1) * y];
-		uint8_t ft = src[0];
-		++src;
-		uint8_t *dst = &img[stride * y];
-		const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
-		for(size_t i = 0; i < stride; ++i)
+		const size_t pw = interlace ? (w - xo[p] + xs[p] - 1) / xs[p] : w, ph = interlace ? (h - yo[p] + ys[p] - 1) / ys[p] : h;
+		if(pw && ph) raw_size += ((pw * bits_px + 7) / 8 + 1) * ph;
+	}
+	std::vector<uint8_t> raw(raw_size);
+	uLongf rawlen = (uLongf)raw.size();
+	if(uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) { *err = "PNG inflate failed"; return false; }
+	std::vector<uint8_t> samples((size_t)w * h * ch); // 8 bits per channel
+	const uint8_t grey_scale = (ctype == 0 && depth < 8) ? (depth == 1 ? 0xff : depth == 2 ? 0x55 : 0x11) : 1;
+	size_t rp = 0;
+	std::vector<uint8_t> cur, prev;
+	for(int p = 0; p < n_pass; ++p)
+	{
+		const size_t pw = interlace ? (w - xo[p] + xs[p] - 1) / xs[p] : w, ph = interlace ? (h - yo[p] + ys[p] - 1) / ys[p] : h;
+		if(!pw || !ph) continue;
+		const size_t stride = (pw * bits_px + 7) / 8;
+		cur.assign(stride, 0); prev.assign(stride, 0);
+		for(size_t y = 0; y < ph; ++y)
 		{
-			int a = i >= bpp ? dst[i - bpp] : 0, bb = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0, pr = 0;
-			switch(ft)
+			const uint8_t ft = raw[rp++];
+			const uint8_t *src = &raw[rp];
+			rp += stride;
+			for(size_t i = 0; i < stride; ++i)
 			{
-				case 0: pr = 0; break;
-				case 1: pr = a; break;
-				case 2: pr = bb; break;
-				case 3: pr = (a + bb) >> 1; break;
-				case 4: { int p = a + bb - c, pa = abs(p - a), pb = abs(p - bb), pc = abs(p - c); pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c); break; }
-				default: *err = "bad PNG filter"; return false;
+				const int a = i >= bpp ? cur[i - bpp] : 0, bb = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+				int pr = 0;
+				switch(ft)
+				{
+					case 0: pr = 0; break;
+					case 1: pr = a; break;
+					case 2: pr = bb; break;
+					case 3: pr = (a + bb) >> 1; break;
+					case 4: { const int q = a + bb - c, pa = abs(q - a), pb = abs(q - bb), pc = abs(q - c); pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c); break; }
+					default: *err = "bad PNG filter"; return false;
+				}
+				cur[i] = (uint8_t)(src[i] + pr);
 			}
-			dst[i] = (uint8_t)(src[i] + pr);
+			const size_t oy = interlace ? (size_t)yo[p] + y * ys[p] : y;
+			for(size_t x = 0; x < pw; ++x)
+			{
+				const size_t ox = interlace ? (size_t)xo[p] + x * xs[p] : x;
+				uint8_t *o = &samples[(oy * w + ox) * ch];
+				if(depth == 8) for(int k = 0; k < ch; ++k) o[k] = cur[x * ch + k];
+				else if(depth == 16) for(int k = 0; k < ch; ++k) o[k] = cur[(x * ch + k) * 2]; // high byte
+				else
+				{
+					const size_t bit = x * depth;
+					o[0] = (uint8_t)(((cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1)) * grey_scale);
+				}
+			}
+			cur.swap(prev);
 		}
 	}
 	out->w = (int)w; out->h = (int)h;
 	out->rgb.resize((size_t)w * h * 3);
-	const size_t bs = depth / 8;
 	for(size_t i = 0; i < (size_t)w * h; ++i)
 	{
-		const uint8_t *p = &img[i * bpp];
+		const uint8_t *p = &samples[i * ch];
 		uint8_t *o = &out->rgb[i * 3];
 		if(ctype == 3)
 		{
-			size_t k = (size_t)p[0] * 3;
+			const size_t k = (size_t)p[0] * 3;
 			if(k + 2 < plte.size()) { o[0] = plte[k]; o[1] = plte[k + 1]; o[2] = plte[k + 2]; }
 			else o[0] = o[1] = o[2] = 0;
 		}
 		else if(ch <= 2) o[0] = o[1] = o[2] = p[0];
-		else { o[0] = p[0]; o[1] = p[bs]; o[2] = p[2 * bs]; }
+		else { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
 	}
 	return true;
 }

@@ -57,7 +57,7 @@ int32_t adypt_scene_textures(const adypt_scene *s, const void **tex /* adypt_tex
 void adypt_scene_aabb(const adypt_scene *s, float lo[3], float hi[3]);
 /* "" or one line per diffuse texture that could not be decoded: like the reference after a failed stbi_load
  * (src/Tracer/OglScene.cpp:12-43) the scene still loads and the material renders with Kd = 0, but the loss is reported
- * (this loader reads PNM, PNG, BMP, TGA and JPEG with stb_image's pixels; stb_image also reads interlaced / sub-byte PNG, GIF, PSD, HDR, PIC) */
+ * (this loader reads PNM, PNG, BMP, TGA and JPEG with stb_image's pixels; stb_image also reads GIF, PSD, HDR, PIC and 16-bit BMP) */
 const char *adypt_scene_warnings(const adypt_scene *s);
 /* wrap caller-provided triangles (no OBJ): used for huge procedural scenes */
 int adypt_scene_from_arrays(const void *tris, int64_t n_tris, const void *mats, int64_t n_mats, adypt_scene **out);
@@ -102,8 +102,8 @@ int adypt_save_exr(const char *path, const float *rgb, int width, int height, in
 int adypt_save_png(const char *path, const uint8_t *rgba8, int width, int height);
 /* minimal reader of the files adypt_save_exr writes (round-trip tests / tools) */
 /* stbi_load(filename, &w, &h, &channels, 3) as OglScene::load_texture calls it (src/Tracer/OglScene.cpp:26-34): tightly packed RGB8, row 0
- * = top.  PNM, PNG, BMP, TGA, JPEG (baseline / progressive; stb_image's own IDCT, up-sampling and colour arithmetic, pinned to it by
- * tests/golden/images).  *rgb is released with adypt_free. */
+ * = top.  PNM, PNG (all depths, Adam7), BMP, TGA, JPEG (baseline / progressive; stb_image's own IDCT, up-sampling and colour arithmetic),
+ * all pinned to the reference's stb_image by tests/golden/images.  *rgb is released with adypt_free. */
 int adypt_load_image_rgb8(const char *path, uint8_t **rgb, int32_t *width, int32_t *height);
 int adypt_load_exr(const char *path, float **rgb, int *width, int *height);
 void adypt_free(void *p);

@@ -94,14 +94,92 @@ def main():
     save("p_grey_alpha", "png", p[..., :2], "LA", "PNG")
     b = io.BytesIO(); Image.fromarray(p, "RGB").quantize(64).save(b, "PNG"); emit("p_palette", "png", b.getvalue())
     b = io.BytesIO(); Image.fromarray((p[..., 0].astype(np.uint16) * 257), "I;16").save(b, "PNG"); emit("p_grey16", "png", b.getvalue())
+    for bits, colours in ((1, 2), (2, 4), (4, 16)):
+        b = io.BytesIO(); Image.fromarray(p, "RGB").quantize(colours).save(b, "PNG", bits=bits); emit("p_palette%d" % bits, "png", b.getvalue())
+    b = io.BytesIO(); Image.fromarray(p[..., 0] > 120).save(b, "PNG"); emit("p_grey1", "png", b.getvalue())
+    for bits in (2, 4):   # grey at 2 and 4 bits: written by hand (filter 0), Pillow only writes them as palettes
+        emit("p_grey%d" % bits, "png", raw_png(p[..., 1] >> (8 - bits), bits, 0, interlace=False))
+    for nm, arr, depth, ctype in (("p_rgb_adam7", p, 8, 2), ("p_grey_adam7", p[..., 2], 8, 0), ("p_grey4_adam7", p[..., 0] >> 4, 4, 0),
+                                  ("p_rgba16_adam7", np.concatenate([p, p[..., :1]], -1).astype(np.uint16) * 257 + 3, 16, 6)):
+        emit(nm, "png", raw_png(arr, depth, ctype, interlace=True))
+    emit("p_adam7_1x1", "png", raw_png(p[:1, :1], 8, 2, interlace=True))
+    emit("p_adam7_3x5", "png", raw_png(p[:5, :3], 8, 2, interlace=True))
     save("b_rgb", "bmp", p, "RGB", "BMP")
+    save("b_grey8", "bmp", p[..., 1], "L", "BMP")
+    b = io.BytesIO(); Image.fromarray(p, "RGB").quantize(50).save(b, "BMP"); emit("b_palette8", "bmp", b.getvalue())
+    # 4-bit palettised and top-down 32-bit: by hand
+    import struct
+    q16 = np.asarray(Image.fromarray(p, "RGB").quantize(16))
+    pal16 = np.asarray(Image.fromarray(p, "RGB").quantize(16).getpalette()[:48], np.uint8).reshape(16, 3)
+    hh, ww = q16.shape
+    rows = b""
+    for yy in range(hh - 1, -1, -1):
+        r = q16[yy].astype(np.uint8)
+        if ww % 2: r = np.append(r, 0)
+        packed = (r[0::2] << 4 | r[1::2]).astype(np.uint8).tobytes()
+        rows += packed + b"\0" * (-len(packed) % 4)
+    palb = b"".join(bytes([c[2], c[1], c[0], 0]) for c in pal16)
+    off = 14 + 40 + len(palb)
+    emit("b_palette4", "bmp", b"BM" + struct.pack("<IHHI", off + len(rows), 0, 0, off) + struct.pack("<IiiHHIIiiII", 40, ww, hh, 1, 4, 0, len(rows), 2835, 2835, 16, 0) + palb + rows)
+    bgra = np.concatenate([p[..., ::-1], np.full(p.shape[:2] + (1,), 255, np.uint8)], -1)
+    emit("b_rgb32_topdown", "bmp", b"BM" + struct.pack("<IHHI", 54 + bgra.size, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, ww, -hh, 1, 32, 0, bgra.size, 2835, 2835, 0, 0) + bgra.tobytes())
     save("t_rgb", "tga", p, "RGB", "TGA")
     save("t_rgb_rle", "tga", p, "RGB", "TGA", compression="tga_rle")
     save("t_rgba", "tga", np.concatenate([p, picture(23, 19, 22)[..., :1]], -1), "RGBA", "TGA")
     save("t_grey", "tga", p[..., 2], "L", "TGA")
+    b = io.BytesIO(); Image.fromarray(p, "RGB").quantize(40).save(b, "TGA"); emit("t_palette", "tga", b.getvalue())
+    b = io.BytesIO(); Image.fromarray(p, "RGB").quantize(200).save(b, "TGA", compression="tga_rle"); emit("t_palette_rle", "tga", b.getvalue())
+    # 16-bit 5-5-5 true colour, 16-bit grey + alpha, 16-bit palette entries: written by hand (18-byte header, bottom-up rows)
+    def tga(type_, bpp, body, cmap=b"", pal_len=0, pal_bits=0, desc=0):
+        hh, ww = p.shape[:2]
+        return bytes([0, 1 if cmap else 0, type_, 0, 0, pal_len & 255, pal_len >> 8, pal_bits, 0, 0, 0, 0, ww & 255, ww >> 8, hh & 255, hh >> 8, bpp, desc]) + cmap + body
+    v555 = ((p[..., 0].astype(np.uint16) >> 3) << 10 | (p[..., 1].astype(np.uint16) >> 3) << 5 | (p[..., 2].astype(np.uint16) >> 3))
+    emit("t_rgb555", "tga", tga(2, 16, v555[::-1].astype("<u2").tobytes()))
+    emit("t_rgb555_top", "tga", tga(2, 15, v555.astype("<u2").tobytes(), desc=0x20))
+    emit("t_grey_alpha16", "tga", tga(3, 16, np.stack([p[..., 0], p[..., 1]], -1)[::-1].tobytes()))
+    pal = (np.arange(64, dtype=np.uint16) * 511 % 32768).astype("<u2")
+    emit("t_palette16", "tga", tga(1, 8, (p[..., 2] >> 2)[::-1].astype(np.uint8).tobytes(), cmap=pal.tobytes(), pal_len=64, pal_bits=16))
+    emit("t_palette_overrun", "tga", tga(1, 8, (p[..., 2])[::-1].astype(np.uint8).tobytes(), cmap=bytes(range(30)) , pal_len=10, pal_bits=24))
     with open(os.path.join(OUT, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
     print(len(index), "fixtures,", sum(os.path.getsize(os.path.join(OUT, n)) for n in os.listdir(OUT)), "bytes")
+
+
+def raw_png(arr, depth, ctype, interlace):
+    """PNG writer for the variants Pillow cannot produce: any depth / colour type, Adam7, filter type 0 on every row."""
+    import struct
+    import zlib
+    arr = np.asarray(arr)
+    if arr.ndim == 2:
+        arr = arr[..., None]
+    h, w, ch = arr.shape
+
+    def pack_rows(a):
+        rows = bytearray()
+        for row in a:
+            rows.append(0)
+            flat = row.reshape(-1)
+            if depth == 8:
+                rows.extend(flat.astype(np.uint8).tobytes())
+            elif depth == 16:
+                rows.extend(flat.astype(">u2").tobytes())
+            else:
+                bits = "".join(format(int(v), "0%db" % depth) for v in flat)
+                bits += "0" * (-len(bits) % 8)
+                rows.extend(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+        return bytes(rows)
+
+    if interlace:
+        xo, yo, xs, ys = (0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)
+        data = b"".join(pack_rows(arr[yo[k]::ys[k], xo[k]::xs[k]]) for k in range(7) if arr[yo[k]::ys[k], xo[k]::xs[k]].size)
+    else:
+        data = pack_rows(arr)
+
+    def chunk(tag, payload):
+        return struct.pack(">I", len(payload)) + tag + payload + struct.pack(">I", zlib.crc32(tag + payload) & 0xffffffff)
+
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0)) +
+            chunk(b"IDAT", zlib.compress(data)) + chunk(b"IEND", b""))
 
 
 # ---- a minimal baseline JPEG ENCODER (fixture generation only) with arbitrary sampling factors --------------------------------------
