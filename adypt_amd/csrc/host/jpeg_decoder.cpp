@@ -131,9 +131,9 @@ inline uint8_t clamp8(int x) { return x < 0 ? 0 : x > 255 ? 255 : (uint8_t)x; }
 // stb_image.h:2110-2206 (its scalar, SSE2 and NEON kernels are bit-identical by construction): jidctint's "islow" butterflies
 // with 12-bit constants; the column pass keeps 2 extra bits ((x + 512) >> 10), the row pass removes 17 with the +128 level shift
 // folded into the rounding constant; columns whose AC terms are all zero short-cut to dc << 2.
-#define ADYPT_F2F(x) ((int)((x) * 4096 + 0.5))
+#define ADYPT_F2F(x) ((long long)((x) * 4096 + 0.5))
 #define ADYPT_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                  \
-	int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                            \
+	long long t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3; /* 64-bit: a corrupt stream cannot overflow them */ \
 	p2 = s2; p3 = s6;                                                                                  \
 	p1 = (p2 + p3) * ADYPT_F2F(0.5411961f);                                                            \
 	t2 = p1 + p3 * ADYPT_F2F(-1.847759065f);                                                           \
@@ -150,16 +150,18 @@ inline uint8_t clamp8(int x) { return x < 0 ? 0 : x > 255 ? 255 : (uint8_t)x; }
 	p3 = p3 * ADYPT_F2F(-1.961570560f); p4 = p4 * ADYPT_F2F(-0.390180644f);                            \
 	t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
 
+inline uint8_t clamp8(long long x) { return x < 0 ? 0 : x > 255 ? 255 : (uint8_t)x; }
+
 void idct_block(uint8_t *out, int stride, const int16_t d[64])
 {
-	int val[64];
+	long long val[64];
 	for(int i = 0; i < 8; ++i)
 	{
 		const int16_t *c = d + i;
-		int *v = val + i;
+		long long *v = val + i;
 		if(c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0)
 		{
-			const int dc = c[0] * 4;
+			const long long dc = c[0] * 4;
 			v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
 		}
 		else
@@ -174,7 +176,7 @@ void idct_block(uint8_t *out, int stride, const int16_t d[64])
 	}
 	for(int i = 0; i < 8; ++i)
 	{
-		const int *v = val + i * 8;
+		const long long *v = val + i * 8;
 		uint8_t *o = out + (size_t)i * stride;
 		ADYPT_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
 		x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
