@@ -302,10 +302,10 @@ int adypt_bvh_load(const char *path, const adypt_bvh_params *expected, adypt_bvh
 	if(hdr + (size_t)n * 4 > buf.size()) { set_host_error("truncated bvh cache"); return ADYPT_E_PARSE; }
 	adypt_bvh *b = new adypt_bvh();
 	b->tri_indices.resize(n);
-	memcpy(b->tri_indices.data(), buf.data() + hdr, (size_t)n * 4);
+	if(n) memcpy(b->tri_indices.data(), buf.data() + hdr, (size_t)n * 4);
 	size_t rest = buf.size() - hdr - (size_t)n * 4;
 	b->nodes.resize(rest / sizeof(NodeRec));
-	memcpy(b->nodes.data(), buf.data() + hdr + (size_t)n * 4, b->nodes.size() * sizeof(NodeRec));
+	if(!b->nodes.empty()) memcpy(b->nodes.data(), buf.data() + hdr + (size_t)n * 4, b->nodes.size() * sizeof(NodeRec));
 	*out = b;
 	return ADYPT_OK;
 }

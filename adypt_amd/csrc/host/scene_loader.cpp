@@ -350,6 +350,15 @@ static bool load_obj(const char *path, SceneData *sc, std::string *err)
 				for(int c = 0; c < 3; ++c)
 				{
 					const Corner &cn = tri_corners[k + (size_t)c];
+					// tinyobj stores whatever index the file gives and the reference's Scene.cpp then reads attrib.vertices[3 * idx]
+					// unchecked (src/Util/Scene.cpp:60-75): an index outside the vertices defined so far is undefined behaviour there,
+					// an error here
+					if(cn.v < 0 || 3 * (size_t)cn.v + 2 >= v.size() || cn.vn < -1 || (cn.vn >= 0 && 3 * (size_t)cn.vn + 2 >= vn.size()) ||
+					   cn.vt < -1 || (cn.vt >= 0 && 2 * (size_t)cn.vt + 1 >= vt.size()))
+					{
+						*err = "`f' line references a vertex / normal / texture coordinate that is not defined";
+						return false;
+					}
 					tr.p[c] = {v[3 * (size_t)cn.v], v[3 * (size_t)cn.v + 1], v[3 * (size_t)cn.v + 2]};
 					if(cn.vn != -1) tr.n[c] = {vn[3 * (size_t)cn.vn], vn[3 * (size_t)cn.vn + 1], vn[3 * (size_t)cn.vn + 2]};
 					if(cn.vt != -1) { tr.tc[c][0] = vt[2 * (size_t)cn.vt]; tr.tc[c][1] = 1.0f - vt[2 * (size_t)cn.vt + 1]; }

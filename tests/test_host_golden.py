@@ -311,3 +311,14 @@ def test_corrupt_jpegs_fail_cleanly(tmp_path):
             assert img.ndim == 3 and img.shape[2] == 3
         except N.AdyptError:
             pass
+
+
+def test_obj_face_index_out_of_range_is_an_error(tmp_path):
+    """tinyobj stores whatever index a face gives and the reference's Scene.cpp reads attrib.vertices[3 * idx] unchecked
+    (src/Util/Scene.cpp:60-75): undefined behaviour there, a load error here (found by tools/fuzz_loaders.cpp)."""
+    for face in ("f 1 2 9", "f 1 2 -7", "f 1/5 2/1 3/1", "f 1//4 2//1 3//1"):
+        (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\n%s\n" % face)
+        assert not api.Scene().LoadFromFile(str(tmp_path / "bad.obj")), face
+        assert "not defined" in api.InstanceConfig.last_error()
+    (tmp_path / "ok.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 -1/-1/-1\n")
+    assert api.Scene().LoadFromFile(str(tmp_path / "ok.obj"))
