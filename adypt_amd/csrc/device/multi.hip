@@ -159,6 +159,7 @@ void park_comm(adypt_ctx *ctx, Comm *k)
 int assemble_on_root(adypt_ctx *ctx, Comm *k)
 {
 	const CtxInfo i = ctx_info(ctx);
+	HIP_OK(ctx, hipSetDevice(i.device));
 	if(i.n_local_px > 0)
 		HIP_OK(ctx, hipMemcpyAsync(k->gathered, i.accum, (size_t)i.n_local_px * sizeof(float4), hipMemcpyDeviceToDevice, i.stream));
 	// pixels no rank owns do not exist (every block has an owner); the image is fully overwritten
