@@ -177,6 +177,7 @@ struct adypt_multi {
 	std::vector<int> devices;
 	std::string error;
 	bool comms_ready = false;
+	bool shared_device = false; // test hook (ADYPT_MULTI_SHARED_DEVICE=1): several shards on ONE device; the exchange is a device copy
 	int spp = 0;
 };
 
@@ -218,10 +219,15 @@ int adypt_create_multi(adypt_multi **out, const adypt_scene_desc *desc, const in
 	g_multi_error.clear();
 	if(!out || !desc || !device_ids || n_dev < 1 || n_dev > 64) { g_multi_error = "adypt_create_multi: bad arguments"; return ADYPT_E_INVALID; }
 	*out = nullptr;
+	// RCCL refuses two ranks on one device.  ADYPT_MULTI_SHARED_DEVICE=1 is a test hook for boxes with a single GPU: the same fan-out,
+	// sharding, ordering and un-tiling, with the peer -> root transfers done by device-to-device copies instead of ncclSend / ncclRecv.
+	const char *shared_env = getenv("ADYPT_MULTI_SHARED_DEVICE");
+	const bool shared = shared_env && atoi(shared_env) != 0;
 	for(int i = 0; i < n_dev; ++i)
 		for(int j = 0; j < i; ++j)
-			if(device_ids[i] == device_ids[j]) { g_multi_error = "adypt_create_multi: device listed twice (RCCL needs distinct devices)"; return ADYPT_E_INVALID; }
+			if(device_ids[i] == device_ids[j] && !shared) { g_multi_error = "adypt_create_multi: device listed twice (RCCL needs distinct devices)"; return ADYPT_E_INVALID; }
 	adypt_multi *m = new adypt_multi();
+	m->shared_device = shared;
 	for(int i = 0; i < n_dev; ++i)
 	{
 		adypt_scene_desc d = *desc;
@@ -280,6 +286,7 @@ int adypt_multi_trace_spp(adypt_multi *m, int n_spp)
 int adypt_multi_comm_init(adypt_multi *m)
 {
 	if(!m) return ADYPT_E_INVALID;
+	if(m->shared_device) return mfail(m, ADYPT_E_STATE, "adypt_multi_comm_init: no RCCL communicator in the shared-device test mode (RCCL needs distinct devices)");
 	return multi_comm_init(m);
 }
 
@@ -289,9 +296,10 @@ int adypt_multi_gather_radiance(adypt_multi *m, void **rgb_device)
 	*rgb_device = nullptr;
 	const int n = (int)m->ctx.size();
 	adypt_ctx *root = m->ctx[0];
-	if(n == 1 && !m->comms_ready)
+	if((n == 1 || m->shared_device) && !m->comms_ready)
 	{
-		// a single device has nothing to exchange: root-side buffers only, no communicator
+		// a single device has nothing to exchange (and the shared-device test hook exchanges by device copies): root-side buffers
+		// only, no communicator
 		if(!comm_of(root))
 		{
 			Comm *k = new Comm();
@@ -306,7 +314,20 @@ int adypt_multi_gather_radiance(adypt_multi *m, void **rgb_device)
 		if(r != ADYPT_OK) return r;
 	}
 	Comm *k0 = comm_of(root);
-	if(n > 1)
+	if(n > 1 && m->shared_device)
+	{
+		for(int r = 1; r < n; ++r)
+		{
+			const CtxInfo pi = ctx_info(m->ctx[(size_t)r]);
+			if(pi.n_local_px == 0) continue;
+			int w = adypt_wait(m->ctx[(size_t)r]); // the peer's frames are done (its stream is not the root's)
+			if(w != ADYPT_OK) return mfail_ctx(m, w, m->ctx[(size_t)r]);
+			const CtxInfo ri = ctx_info(root);
+			if(hipMemcpyAsync(k0->gathered + (size_t)r * (size_t)k0->stride, pi.accum, (size_t)pi.n_local_px * sizeof(float4), hipMemcpyDeviceToDevice, ri.stream) != hipSuccess)
+				return mfail(m, ADYPT_E_HIP, "shared-device gather: copy failed");
+		}
+	}
+	else if(n > 1)
 	{
 		// the one exchange: grouped point-to-point = ncclGather with exact per-rank sizes; peer r -> root over its own link
 		RcclApi *api = k0->api;

@@ -204,7 +204,9 @@ int adypt_untile_host(int width, int height, int rank, int nranks, const float *
  *
  * (1) One process, N devices — what a C++ host such as the reference's Instance (src/Instance.cpp:33-57) needs to use more
  * than one GPU: one adypt_multi stands for N contexts (tile rank i on device_ids[i], scene replicated), every call fans out
- * to all of them from the calling thread (the per-device work is asynchronous), adypt_multi_read_radiance gathers. */
+ * to all of them from the calling thread (the per-device work is asynchronous), adypt_multi_read_radiance gathers.
+ * Test hook for single-GPU machines: with ADYPT_MULTI_SHARED_DEVICE=1 in the environment a device may be listed several times
+ * (RCCL refuses that); the shards then share the device and the peer -> root transfers are device-to-device copies. */
 typedef struct adypt_multi adypt_multi;
 int adypt_create_multi(adypt_multi **out, const adypt_scene_desc *desc /* device, tile_rank, tile_nranks ignored */,
                        const int *device_ids, int n_dev);

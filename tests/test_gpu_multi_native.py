@@ -88,3 +88,36 @@ def test_comm_api_single_rank(scene_cache):
     with pytest.raises(N.AdyptError) as e:
         part.m_path_tracer.CommGatherDevice()
     assert e.value.code == N.E_STATE
+
+
+@pytest.mark.parametrize("name,w,h,n_dev", [("tiny0", 200, 120, 3), ("sponza", 320, 200, 2), ("tiny0", 64, 36, 4), ("sibenik", 160, 90, 8)])
+def test_multi_fan_out_on_one_device(name, w, h, n_dev, scene_cache, sobol_matrices, monkeypatch):
+    """Everything of adypt_multi except the RCCL transport, with N > 1, on the one GPU a test box has (ADYPT_MULTI_SHARED_DEVICE:
+    the shards share the device, the peer -> root transfers are device copies): the fan-out of every call, the tile shards
+    (including shards that own no block: 64x36 on 4), the gather layout and the un-tiling must reproduce the 1-context frames."""
+    monkeypatch.setenv("ADYPT_MULTI_SHARED_DEVICE", "1")
+    inst = make_instance(scene_cache, name, w, h, pt={"maxBounce": 5, "stackSize": 24, "tmpLifetime": 3})
+    c = inst.m_config.c
+    m = _multi(inst, devices=(0,) * n_dev)
+    assert m.DeviceCount() == n_dev
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    m.m_viewer_type = 4
+    m.Trace(False)
+    rgba, _, _ = O.primary_frame(osc, P, 4)
+    assert np.array_equal(bits(m.ReadResult()), bits(rgba[..., :3]))
+    m.Trace(True, 7)
+    st = O.PathTracerState(c.width, c.height)
+    ost = O.pt_frames(osc, P, O.shift_bytes(99, c.width, c.height), sobol_matrices, st, 7).as_dict()
+    assert np.array_equal(bits(m.ReadResult()), bits(st.accum[..., :3])) and m.GetSPP() == 7
+    assert sum(m.ContextStats(i)["rays"] for i in range(n_dev)) == ost["rays"] + c.width * c.height  # + the viewer frame's primaries
+    # one frame per call with look-ahead on every shard
+    m.Reset()
+    m.SetLookahead(True)
+    st2 = O.PathTracerState(c.width, c.height)
+    for _ in range(4):
+        m.Trace(True, 1)
+        O.pt_frames(osc, P, O.shift_bytes(99, c.width, c.height), sobol_matrices, st2, 1)
+        assert np.array_equal(bits(m.ReadResult()), bits(st2.accum[..., :3]))
+    with pytest.raises(N.AdyptError):
+        m.CommInit()  # no communicator in this mode
+    m.destroy()
