@@ -179,7 +179,9 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			continue;
 		}
 
-		if(active)
+		// No `if(active)` around the trip: a lane without a ray carries an inert state (no triangles, nothing pending, empty group,
+		// empty stack), so every step below is a no-op for it — and it stays available as a HELPER for its neighbour's second
+		// triangle (C), which needs every lane of the wave enabled when the rays are exchanged.
 		{
 			// One trip = at most one triangle PAIR and at most one slab test per lane.  A lane whose node produced more
 			// than two triangles keeps its already chosen next node pending and simply fetches it again on the following
@@ -231,34 +233,48 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			if(ANY) push_overflow |= push && !push_ok; // an any-hit ray may end before the visit the push belongs to
 			else overflow |= push && !push_ok;         // closest hit: the visit always follows, commit right away
 			// ---------------- B. issue every load of this trip back to back: one triangle pair, then the pending node ------
-			struct TriPair { float4 p0, p1, p2, q0, q1, q2; uint32_t tri0, tri1; bool two; };
+			// The triangle PAIR of a lane is tested by TWO lanes: the lane itself takes its first triangle, its neighbour (lane ^ 1) —
+			// when that one has no triangle of its own this trip, which is the case 4 times out of 5 — takes the second one, with the
+			// owner's ray handed over by DPP quad swaps; the result comes back the same way and the owner applies it AFTER its own, with
+			// the updated hit_t: exactly the sequential order of traversal.glsl:213-243.  Per trip that is 3 triangle loads instead of 6 (the
+			// CU's vector-memory pipeline charges per instruction, not per lane: profiles/r2_l1_patterns_microbench.txt) and one Woop test
+			// instead of two.  A lane whose neighbour is busy with its own triangle keeps its second one for the next trip.
+			auto swap1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }; // quad_perm [1,0,3,2]
+			auto swap1f = [&](float v) { return __uint_as_float(swap1(__float_as_uint(v))); };
 			const bool has_tri = tg_y != 0;
-			TriPair tp;
-			// registers only read under has_tri / pending: "defined" by an empty asm (no instruction) instead of zero-filled —
-			// leaving them uninitialised makes the register allocator spill, zero-filling costs 45 VALU slots per trip
+			const uint32_t tg_rest = tg_y & (tg_y - 1u);
+			const bool two = tg_rest != 0;
+			const uint32_t nb_flags = swap1((has_tri ? 1u : 0u) | (two ? 2u : 0u));
+			const bool coop = two && !(nb_flags & 1u);                  // my second triangle goes to the neighbour
+			const bool helper = !has_tri && nb_flags == 3u;             // I test the neighbour's second triangle
+			const uint32_t own_t0 = tg_x + (uint32_t)__builtin_ctz(tg_y | 0x80000000u);
+			const uint32_t own_t1 = tg_x + (uint32_t)__builtin_ctz(tg_rest | 0x80000000u);
+			const uint32_t nb_t1 = swap1(own_t1);
+			const V2 nb_od_x = v2(swap1f(od_x.x), swap1f(od_x.y)), nb_od_y = v2(swap1f(od_y.x), swap1f(od_y.y)), nb_od_z = v2(swap1f(od_z.x), swap1f(od_z.y));
+			const float nb_tmin = swap1f(tmin);
+			if(has_tri) tg_y = coop ? (tg_rest & (tg_rest - 1u)) : tg_rest; // consumed: the first triangle, and the second if it was handed over
+			const bool do_test = has_tri || helper;
+			const uint32_t tri_sel = helper ? nb_t1 : own_t0;
+			const V2 t_od_x = helper ? nb_od_x : od_x, t_od_y = helper ? nb_od_y : od_y, t_od_z = helper ? nb_od_z : od_z;
+			const float t_tmin = helper ? nb_tmin : tmin;
+			float4 wp0, wp1, wp2;
+			// registers only read under do_test / pending: "defined" by an empty asm (no instruction) instead of zero-filled —
+			// leaving them uninitialised makes the register allocator spill, zero-filling costs VALU slots every trip
 #define ADYPT_DEF4(v) asm volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))
-			ADYPT_DEF4(tp.p0); ADYPT_DEF4(tp.p1); ADYPT_DEF4(tp.p2); ADYPT_DEF4(tp.q0); ADYPT_DEF4(tp.q1); ADYPT_DEF4(tp.q2);
-			asm volatile("" : "=v"(tp.tri0), "=v"(tp.tri1)); tp.two = false;
-			if(has_tri)
+			ADYPT_DEF4(wp0); ADYPT_DEF4(wp1); ADYPT_DEF4(wp2);
+			if(do_test)
 			{
-				const uint32_t b0 = (uint32_t)__builtin_ctz(tg_y);
-				tg_y &= tg_y - 1u;
-				tp.two = tg_y != 0;
-				const uint32_t b1 = tp.two ? (uint32_t)__builtin_ctz(tg_y) : b0;
-				tg_y &= tg_y - 1u; // no-op when tg_y is already 0
-				tp.tri0 = tg_x + b0; tp.tri1 = tg_x + b1;
-				const float4 *w0 = a.woop + (size_t)tp.tri0 * 3, *w1 = a.woop + (size_t)tp.tri1 * 3;
-				tp.p0 = w0[0]; tp.p1 = w0[1]; tp.p2 = w0[2];
+				const float4 *w0 = a.woop + (size_t)tri_sel * 3;
+				wp0 = w0[0]; wp1 = w0[1]; wp2 = w0[2];
 #ifdef ADYPT_ABLATE_EXTRA_TRI_LOADS
-				{	// measurement-only build: the 6 triangle loads a second time (L1 hits)
-					const float4 *x0 = w0, *x1 = w1;
-					asm volatile("" : "+v"(x0), "+v"(x1));
-					const float4 e0 = x0[0], e1 = x0[1], e2 = x0[2], e3 = x1[0], e4 = x1[1], e5 = x1[2];
-					asm volatile("" :: "v"(e0.x), "v"(e0.w), "v"(e1.x), "v"(e1.w), "v"(e2.x), "v"(e2.w), "v"(e3.x), "v"(e3.w), "v"(e4.x), "v"(e4.w), "v"(e5.x), "v"(e5.w));
+				{	// measurement-only build: the triangle loads a second time (L1 hits)
+					const float4 *x0 = w0;
+					asm volatile("" : "+v"(x0));
+					const float4 e0 = x0[0], e1 = x0[1], e2 = x0[2];
+					asm volatile("" :: "v"(e0.x), "v"(e0.w), "v"(e1.x), "v"(e1.w), "v"(e2.x), "v"(e2.w));
 				}
 #endif
-				tp.q0 = w1[0]; tp.q1 = w1[1]; tp.q2 = w1[2]; // unconditional (tri1 == tri0 for a single triangle): a predicated
-			}                                                // second fetch measured 3 % slower (extra branch, split load batch)
+			}
 			uint4 n0, n1, n2, n3, n4;
 			ADYPT_DEF4(n0); ADYPT_DEF4(n1); ADYPT_DEF4(n2); ADYPT_DEF4(n3); ADYPT_DEF4(n4);
 			// The pending node is fetched in the trip that will slab-test it, i.e. once this trip's pair leaves no triangle behind.
@@ -289,39 +305,32 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			}
 			__builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting arithmetic between the load issues
 
-			// ---------------- C. one pair of the triangles of the node visited last (traversal.glsl:213-243) ----------------
-			// Woop test of one triangle (traversal.glsl:219-242)
-			auto test_tri = [&](const float4 &m0, const float4 &m1, const float4 &m2, uint32_t tri) {
-				// (o·m, d·m) per row: x = dot3(origin, m.xyz), y = dot3(dir, m.xyz)
-				const V2 r0 = pk_fma(od_z, v2s(m0.z), pk_fma(od_y, v2s(m0.y), od_x * v2s(m0.x)));
-				const V2 r1 = pk_fma(od_z, v2s(m1.z), pk_fma(od_y, v2s(m1.y), od_x * v2s(m1.x)));
-				const V2 r2 = pk_fma(od_z, v2s(m2.z), pk_fma(od_y, v2s(m2.y), od_x * v2s(m2.x)));
-				const float toz = m0.w - r0.x;
-				const float tidz = 1.0f / r0.y;
-				const float tt = toz * tidz;
-				const float tu = fmaf(tt, r1.y, m1.w + r1.x);
-				const float tv = fmaf(tt, r2.y, m2.w + r2.x);
-				if(tt > tmin && tt < hit_t && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f)
-				{
-					hit_t = tt; hit_u = tu; hit_v = tv; hit_idx = (int32_t)tri;
-				}
-			};
-			if(has_tri)
+			// ---------------- C. triangles of the node visited last (traversal.glsl:213-243): one Woop test per lane ----------------
+			float tt, tu, tv;
+			asm volatile("" : "=v"(tt), "=v"(tu), "=v"(tv));
+			bool geom_ok = false;
+			if(do_test)
 			{
 				if(STATS) wave_event(2);
-				test_tri(tp.p0, tp.p1, tp.p2, tp.tri0);
-				if(ANY && hit_idx != -1)
-				{
-					// first accepted triangle ends the ray: nothing after it is tested or visited (traversal.glsl:477-483)
-					if(STATS) n_tris += 1u;
-				}
-				else
-				{
-					if(tp.two) test_tri(tp.q0, tp.q1, tp.q2, tp.tri1);
-					if(STATS) n_tris += tp.two ? 2u : 1u;
-				}
-				if(ANY && hit_idx != -1) { tg_y = 0; pending = false; }
+				// Woop test (traversal.glsl:219-242); (o·m, d·m) per row: x = dot3(origin, m.xyz), y = dot3(dir, m.xyz)
+				const V2 r0 = pk_fma(t_od_z, v2s(wp0.z), pk_fma(t_od_y, v2s(wp0.y), t_od_x * v2s(wp0.x)));
+				const V2 r1 = pk_fma(t_od_z, v2s(wp1.z), pk_fma(t_od_y, v2s(wp1.y), t_od_x * v2s(wp1.x)));
+				const V2 r2 = pk_fma(t_od_z, v2s(wp2.z), pk_fma(t_od_y, v2s(wp2.y), t_od_x * v2s(wp2.x)));
+				const float toz = wp0.w - r0.x;
+				const float tidz = 1.0f / r0.y;
+				tt = toz * tidz;
+				tu = fmaf(tt, r1.y, wp1.w + r1.x);
+				tv = fmaf(tt, r2.y, wp2.w + r2.x);
+				geom_ok = tt > t_tmin && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f;
 			}
+			if(has_tri && geom_ok && tt < hit_t) { hit_t = tt; hit_u = tu; hit_v = tv; hit_idx = (int32_t)own_t0; }
+			// the neighbour's verdict on my second triangle, applied after my first with the shortened hit_t (NaN = rejected)
+			const float nb_tt = swap1f(geom_ok ? tt : __builtin_nanf("")), nb_tu = swap1f(tu), nb_tv = swap1f(tv);
+			// any-hit: nothing is tested after the first accepted triangle (traversal.glsl:477-483)
+			const bool second = coop && !(ANY && hit_idx != -1);
+			if(second && nb_tt < hit_t) { hit_t = nb_tt; hit_u = nb_tu; hit_v = nb_tv; hit_idx = (int32_t)own_t1; }
+			if(STATS && has_tri) n_tris += second ? 2u : 1u;
+			if(ANY && has_tri && hit_idx != -1) { tg_y = 0; pending = false; }
 
 			if(tg_y != 0)
 			{
@@ -389,8 +398,9 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			// ---------------- E. ray finished (traversal.glsl:245-254)? ----------------
 			// Nothing left to test, to visit or to pop — checked in the SAME trip as the slab test that found no child
 			// (or the triangle pair that was the last work): a separate trip just to notice it cost one of ~13 trips per ray.
-			if(tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))
+			if(active && tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))
 			{
+				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert
 				flush = true; // hit_idx / u / v / t and `ray` stay in their registers until the refill (or the exit) writes them
 				any_overflow |= overflow;
 				if(STATS)
