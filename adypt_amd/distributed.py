@@ -134,7 +134,12 @@ def exchange_unique_id(rank: int, world: int, path: Optional[str] = None, make_i
     if world == 1:
         return make_id()
     if rank == 0:
-        uid = make_id()
+        try:
+            uid = make_id()
+        except Exception:
+            with open(path, "wb") as f:  # tell the waiting ranks at once instead of letting them run into the timeout
+                f.write(b"failed")
+            raise
         tmp = path + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as f:
             f.write(uid)
@@ -147,6 +152,8 @@ def exchange_unique_id(rank: int, world: int, path: Optional[str] = None, make_i
                 uid = f.read()
             if len(uid) == 128:
                 return uid
+            if uid == b"failed":
+                raise RuntimeError("rank 0 could not create an RCCL id (%s)" % path)
         except OSError:
             pass
         if time.time() - t0 > timeout_s:

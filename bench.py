@@ -175,9 +175,11 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     use_torch = world > 1 and args.comm == "torch"
-    dev = local_rank
+    dev = int(os.environ.get("ADYPT_BENCH_DEVICE", local_rank))  # the override only to rehearse N ranks on a 1-GPU box
     dist = torch = None
-    if use_torch:
+
+    def init_torch():
+        nonlocal dist, torch, dev
         import torch
         import torch.distributed as dist
         dev = local_rank % max(1, torch.cuda.device_count())
@@ -188,6 +190,9 @@ def main() -> None:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if use_torch:
+        init_torch()
 
     from adypt_amd import api, distributed as D, scenes, _native as N
 
@@ -207,6 +212,22 @@ def main() -> None:
     fif = pt.GetFramesInFlight()
     t_setup = time.time() - t_setup
 
+    if world > 1 and not use_torch:
+        try:
+            pt.CommInit(D.exchange_unique_id(rank, world))  # the ranks' only exchange outside RCCL: the 128-byte communicator id
+            pt.CommBarrier()
+        except (N.AdyptError, OSError, TimeoutError, RuntimeError) as e:
+            # the library could not bring RCCL up by itself (library not found, symbol missing: the same on every rank): the
+            # torch.distributed variant of the same gather still gives the scaling run a number, and the line says which one ran
+            sys.stderr.write("bench.py rank %d: native RCCL communicator failed (%s); falling back to --comm torch\n" % (rank, e))
+            use_torch = True
+            init_torch()
+        if rank == 0:  # every rank holds the communicator now: a later job must never find this id
+            try:
+                os.remove(D.rendezvous_path())
+            except OSError:
+                pass
+
     if use_torch:
         n_pad = D.max_block_count(c.width, c.height, world) * D.BLOCK_PIXELS * 4
         gather_buf = torch.zeros(n_pad, dtype=torch.float32, device="cuda")
@@ -222,15 +243,6 @@ def main() -> None:
                 return D.gather_radiance_device(gather_buf, pt, c.width, c.height, rank, world)
             return D.gather_radiance(gather_buf, c.width, c.height, rank, world)
     else:
-        if world > 1:
-            pt.CommInit(D.exchange_unique_id(rank, world))  # the ranks' only exchange outside RCCL: the 128-byte communicator id
-            pt.CommBarrier()
-            if rank == 0:  # every rank holds the communicator now: a later job must never find this id
-                try:
-                    os.remove(D.rendezvous_path())
-                except OSError:
-                    pass
-
         def barrier():
             # every rank's GPU drained (hipDeviceSynchronize), then all ranks met (RCCL all-reduce + drain)
             pt.DeviceSynchronize()

@@ -4,6 +4,7 @@ adypt_amd.distributed — the code path bench.py --gpus N uses with the nccl (RC
 import os
 import socket
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -109,3 +110,20 @@ def test_native_rendezvous_file_carries_the_id_between_processes(tmp_path):
     for p in procs:
         p.join(30)
     assert got == {0: bytes(range(128)), 1: bytes(range(128)), 2: bytes(range(128))}
+
+
+def test_native_rendezvous_tells_waiting_ranks_when_rank0_cannot_make_an_id(tmp_path):
+    """bench.py falls back to torch.distributed when the library cannot bring RCCL up: the waiting ranks must learn that at
+    once (not after the timeout), so every rank takes the same branch."""
+    from adypt_amd import distributed as D
+    path = str(tmp_path / "id")
+
+    def broken():
+        raise OSError("librccl.so not found")
+
+    with pytest.raises(OSError):
+        D.exchange_unique_id(0, 2, path=path, make_id=broken)
+    t0 = time.time()
+    with pytest.raises(RuntimeError):
+        D.exchange_unique_id(1, 2, path=path, timeout_s=30.0)
+    assert time.time() - t0 < 5.0
