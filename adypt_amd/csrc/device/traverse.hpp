@@ -10,9 +10,12 @@
 //     to idle lanes without further atomics): a per-refill atomic was measured 2.5x slower end to end.
 //   * software-pipelined node fetch: which node comes next (closest remaining child of the current group, or the
 //     popped group) is decided by the *previous* slab test and does not depend on the triangle tests in between, so
-//     its 5 x 16-byte loads are issued together with the loads of the first two triangles of the current node and
-//     the latencies overlap.  The slab test itself still runs after the triangle tests (it needs the shortened
-//     hit_t), exactly like the reference.
+//     its 5 x 16-byte loads are issued together with the triangle loads of the current node and the latencies
+//     overlap.  The slab test itself still runs after the triangle tests (it needs the shortened hit_t), exactly
+//     like the reference.
+//   * cooperative triangle pair: a lane tests one triangle per trip and hands a second one to its neighbour (lane ^ 1)
+//     when that lane has none of its own (DPP quad swaps of the ray and of the result, no LDS); the owner applies
+//     its own result first, then the neighbour's — the reference's order (section B / C below).
 //   * the node-group stack lives in LDS, laid out [depth][lane] (ds_write_b64 / ds_read_b64, conflict free); only
 //     entries deeper than kLdsStackMax spill to a global scratch array.  Overflow beyond stackSize is reported.
 //   * XCD-affine queue segments with separate fetch cursors on separate cache lines (see shade.hpp).
@@ -183,10 +186,10 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 		// empty stack), so every step below is a no-op for it — and it stays available as a HELPER for its neighbour's second
 		// triangle (C), which needs every lane of the wave enabled when the rays are exchanged.
 		{
-			// One trip = at most one triangle PAIR and at most one slab test per lane.  A lane whose node produced more
-			// than two triangles keeps its already chosen next node pending and simply fetches it again on the following
-			// trip (an L1/L2 hit): measured with adypt_get_wave_profile, an inner loop over all pairs ran 2.4 iterations per
-			// trip with 6 of 64 lanes live — 40 % of the kernel's VALU slots at 9 % utilisation.
+			// One trip = at most one triangle PAIR (the lane's own test + its neighbour's) and at most one slab test per lane.
+			// A lane whose node produced more triangles than the trip consumes keeps its already chosen next node pending
+			// (fetched in the trip that slab-tests it): measured with adypt_get_wave_profile, an inner loop over all pairs ran
+			// 2.4 iterations per trip with 6 of 64 lanes live — 40 % of the kernel's VALU slots at 9 % utilisation.
 			// ---------------- A. choose the next node (traversal.glsl:47-66 / 245-250) unless one is pending ----------------
 			// (flat sequence of predicated steps rather than nested branches: every nesting level made the compiler copy
 			// the loop-carried ray state)
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 
 			if(tg_y != 0)
 			{
-				// more triangles of this node: next trip (the pending node is fetched again then)
+				// more triangles of this node: next trip (the pending node is fetched in the trip that consumes the last of them)
 			}
 			else if(pending)
 			{
