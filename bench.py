@@ -303,7 +303,8 @@ def main() -> None:
     # The PMC counters cannot be read from inside this process: per-ray figures come from the committed rocprofv3 --pmc passes
     # over this very command line (tools/collect_profiles.sh -> profiles/r2_pmc_bench.json) x the rays / time measured here.
     pmc = load_profile("r2_pmc_bench.json")
-    use_pmc = pmc if (pmc and world == 1 and (args.scene, args.width, args.height) == ("sponza", 1920, 1080)) else None
+    # N > 1: rank 0 traces an interleaved 1/N of the same pixels with the same kernel: the per-ray figures of the N = 1 passes hold
+    use_pmc = pmc if (pmc and (args.scene, args.width, args.height) == ("sponza", 1920, 1080)) else None
     mix = load_profile("r2_k_trace_instruction_mix.json")
     if use_pmc and mix and "valu_insts_per_ray" in use_pmc:
         # vector-ALU issue cycles demanded per second = instructions per ray (PMC) x rays/s (measured here) x average issue cycles of
@@ -330,7 +331,7 @@ def main() -> None:
                         "(vmem_busy_est; ablations in profiles/r2_ablations_k_trace.txt).  achieved = PMC SQ_INSTS_VALU per ray (%s) x the kernel's "
                         "measured rays/s x the average issue cycles of its instruction mix (profiles/r2_k_trace_instruction_mix.json), peak = 1024 SIMDs "
                         "x 2.4 GHz; lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU): the part of every issued instruction that does work"
-                        % (bvh_mb, (use_pmc or {}).get("command", "no committed PMC file for this configuration")))
+                        % (bvh_mb, (use_pmc or {}).get("command", "no committed PMC file for this configuration") + ("; per-ray figures of the 1-GPU passes applied to rank 0's shard" if use_pmc and world > 1 else "")))
 
     # ---- one frame per call (Instance::Update -> Trace(true), src/Instance.cpp:44-57) with the library's look-ahead ----------
     single = None
