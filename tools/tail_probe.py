@@ -27,7 +27,7 @@ print(json.dumps({"nodes_mean": float(nd.mean()), "tris_mean": float(h["tris"].m
                   "nodes_percentiles_50_90_99_99.9_max": [int(np.percentile(nd, q)) for q in (50, 90, 99, 99.9)] + [int(nd.max())]}))
 p.SetInstrumentation(timing=True)
 pts = []
-for n in (1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 23):
+for n in (64, 4096, 1 << 15, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 23):
     p.TraceRays(rays[:n], with_stats=False)
     best = 1e9
     for _ in range(3):
@@ -37,6 +37,6 @@ for n in (1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 23):
     pts.append((n, best))
     print(json.dumps({"rays": n, "kernel_ms": round(best, 4), "Mrays_s": round(n / best / 1e3, 1)}))
     sys.stdout.flush()
-x = np.array([q[0] for q in pts[2:]], float); y = np.array([q[1] for q in pts[2:]], float)
+x = np.array([q[0] for q in pts[5:]], float); y = np.array([q[1] for q in pts[5:]], float)
 b, a = np.polyfit(x, y, 1)
 print(json.dumps({"fit_ms": {"fixed_per_launch": round(a, 4), "per_Mray": round(b * 1e6, 4)}, "asymptotic_Mrays_s": round(1e-3 / b, 1)}))
