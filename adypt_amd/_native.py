@@ -121,6 +121,10 @@ _SIGS = {
     "adypt_multi_trace_spp": (C.c_int, [C.c_void_p, C.c_int]),
     "adypt_multi_reset": (C.c_int, [C.c_void_p]),
     "adypt_multi_get_spp": (C.c_int, [C.c_void_p]),
+    "adypt_multi_set_sun_visibility": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "adypt_multi_set_instrumentation": (C.c_int, [C.c_void_p, C.c_int]),
+    "adypt_multi_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "adypt_multi_read_display": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adypt_multi_read_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adypt_multi_gather_radiance": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "adypt_multi_comm_init": (C.c_int, [C.c_void_p]),

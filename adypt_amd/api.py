@@ -551,6 +551,25 @@ class MultiPathTracer:
     def DeviceCount(self) -> int:
         return N.lib.adypt_multi_device_count(self._m)
 
+    def SetSunVisibility(self, enabled: bool, direction=None) -> None:
+        d = None if direction is None else np.ascontiguousarray(direction, dtype=np.float32).reshape(3)
+        self._check(N.lib.adypt_multi_set_sun_visibility(self._m, 1 if enabled else 0, None if d is None else d.ctypes.data))
+
+    def SetInstrumentation(self, timing: bool = False, counters: bool = False) -> None:
+        self._check(N.lib.adypt_multi_set_instrumentation(self._m, (1 if timing else 0) | (2 if counters else 0)))
+
+    def GetStats(self) -> dict:
+        """Counts summed over the devices, kernel times of the slowest one (they run concurrently)."""
+        st = N.Stats()
+        self._check(N.lib.adypt_multi_get_stats(self._m, C.byref(st)))
+        return st.as_dict()
+
+    def ReadDisplay(self) -> np.ndarray:
+        """What the reference's window shows (screen.glsl:15-21), H x W x 4 uint8: every device converts its own tiles."""
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self._check(N.lib.adypt_multi_read_display(self._m, out.ctypes.data))
+        return out
+
     def ContextStats(self, i: int) -> dict:
         st = N.Stats()
         N.check(N.lib.adypt_get_stats(N.lib.adypt_multi_context(self._m, i), C.byref(st)))

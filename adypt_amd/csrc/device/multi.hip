@@ -267,6 +267,27 @@ int adypt_multi_set_params(adypt_multi *m, const adypt_pt_params *p) { FOR_ALL(m
 int adypt_multi_set_camera(adypt_multi *m, const float o[3], const float ip[16], const float iv[16]) { FOR_ALL(m, adypt_set_camera(c, o, ip, iv)); return ADYPT_OK; }
 int adypt_multi_set_lookahead(adypt_multi *m, int enabled) { FOR_ALL(m, adypt_set_lookahead(c, enabled)); return ADYPT_OK; }
 int adypt_multi_reset(adypt_multi *m) { FOR_ALL(m, adypt_reset(c)); return ADYPT_OK; }
+int adypt_multi_set_sun_visibility(adypt_multi *m, int enabled, const float dir[3]) { FOR_ALL(m, adypt_set_sun_visibility(c, enabled, dir)); return ADYPT_OK; }
+int adypt_multi_set_instrumentation(adypt_multi *m, int flags) { FOR_ALL(m, adypt_set_instrumentation(c, flags)); return ADYPT_OK; }
+// every context writes the pixels of its own tiles into the caller's W*H*4 image: together they are the whole window
+int adypt_multi_read_display(adypt_multi *m, uint8_t *rgba8) { if(!rgba8) return ADYPT_E_INVALID; FOR_ALL(m, adypt_read_display(c, rgba8)); return ADYPT_OK; }
+int adypt_multi_get_stats(adypt_multi *m, adypt_stats *out)
+{
+	if(!m || !out) return ADYPT_E_INVALID;
+	memset(out, 0, sizeof(*out));
+	for(adypt_ctx *c : m->ctx)
+	{
+		adypt_stats s;
+		const int r = adypt_get_stats(c, &s);
+		if(r != ADYPT_OK) return mfail_ctx(m, r, c);
+		// counts add up over the devices; the devices run concurrently, so times are the slowest device's
+		out->rays += s.rays; out->nodes_visited += s.nodes_visited; out->tris_tested += s.tris_tested; out->hits += s.hits; out->shaded += s.shaded;
+		out->stack_overflows += s.stack_overflows; out->bad_materials += s.bad_materials;
+		out->max_stack = std::max(out->max_stack, s.max_stack); out->trace_launches = std::max(out->trace_launches, s.trace_launches);
+		out->trace_ms = std::max(out->trace_ms, s.trace_ms); out->shade_ms = std::max(out->shade_ms, s.shade_ms);
+	}
+	return ADYPT_OK;
+}
 int adypt_multi_get_spp(const adypt_multi *m) { return (m && !m->ctx.empty()) ? adypt_get_spp(m->ctx[0]) : ADYPT_E_INVALID; }
 
 int adypt_multi_trace_primary(adypt_multi *m, int viewer_type)

@@ -220,6 +220,12 @@ int adypt_multi_set_lookahead(adypt_multi *m, int enabled);
 int adypt_multi_trace_primary(adypt_multi *m, int viewer_type);
 int adypt_multi_trace_spp(adypt_multi *m, int n_spp);     /* all devices enqueue, then all are waited for */
 int adypt_multi_reset(adypt_multi *m);
+int adypt_multi_set_sun_visibility(adypt_multi *m, int enabled, const float direction[3]); /* adypt_set_sun_visibility on every device */
+int adypt_multi_set_instrumentation(adypt_multi *m, int flags);
+/* counts summed over the devices; trace_ms / shade_ms / trace_launches / max_stack of the slowest (largest) device — they run concurrently */
+int adypt_multi_get_stats(adypt_multi *m, adypt_stats *out);
+/* adypt_read_display for the whole window: every device converts and writes the pixels of its own tiles into rgba8 (W*H*4) */
+int adypt_multi_read_display(adypt_multi *m, uint8_t *rgba8);
 int adypt_multi_get_spp(const adypt_multi *m);
 /* glGetTextureImage of OglPathTracer::SaveResult (OglPathTracer.cpp:203-205) for the whole image: the gather + un-tiling on
  * device_ids[0], then one device-to-host copy of W*H*3 floats (row 0 = top). */

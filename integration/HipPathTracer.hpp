@@ -158,8 +158,7 @@ public:
 	bool ReadScreen(std::vector<uint8_t> *rgba8) const
 	{
 		rgba8->resize((size_t)m_width * m_height * 4);
-		for(int i = 0; i < adypt_multi_device_count(m_gpus); ++i)
-			if(adypt_read_display(adypt_multi_context(m_gpus, i), rgba8->data()) != ADYPT_OK) return false;
+		if(adypt_multi_read_display(m_gpus, rgba8->data()) != ADYPT_OK) return false; // every device converts and writes its own tiles
 		return true;
 	}
 

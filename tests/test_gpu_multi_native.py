@@ -110,6 +110,8 @@ def test_multi_fan_out_on_one_device(name, w, h, n_dev, scene_cache, sobol_matri
     ost = O.pt_frames(osc, P, O.shift_bytes(99, c.width, c.height), sobol_matrices, st, 7).as_dict()
     assert np.array_equal(bits(m.ReadResult()), bits(st.accum[..., :3])) and m.GetSPP() == 7
     assert sum(m.ContextStats(i)["rays"] for i in range(n_dev)) == ost["rays"] + c.width * c.height  # + the viewer frame's primaries
+    assert m.GetStats()["rays"] == ost["rays"] + c.width * c.height   # adypt_multi_get_stats: counts summed over the devices
+    assert np.array_equal(m.ReadDisplay(), O.display(st.accum, 3))         # every shard converts its own tiles: together the window
     # one frame per call with look-ahead on every shard
     m.Reset()
     m.SetLookahead(True)

@@ -334,6 +334,33 @@ def test_cli_headless_instance(scene_cache, tmp_path):
     assert np.array_equal(bits(api.load_exr(out)), bits(inst.m_path_tracer.ReadResult()))
 
 
+def test_cli_progressive_and_multi_device(scene_cache, tmp_path):
+    """--save-every: the file on disk after every K samples is a complete image, the last one equals a straight render;
+    --devices: the library's multi-device boundary behind the same command line (here three shards on the one GPU of the box)."""
+    import subprocess
+    spec = scenes.make_scene("tiny0", scene_cache, width=100, height=75)
+    exe = os.path.join(os.path.dirname(N.LIB_PATH), "adypt_hip")
+    inst = api.Instance()
+    assert inst.InitializeFromFile(spec.config_path, shift_seed=5)
+    inst.m_path_tracer.Trace(True, 7)
+    want, shown = inst.m_path_tracer.ReadResult(), inst.m_path_tracer.ReadDisplay()
+    for tag, extra, env in (("one", ["--device", "0"], {}), ("three", ["--devices", "0,0,0"], {"ADYPT_MULTI_SHARED_DEVICE": "1"})):
+        out, png = str(tmp_path / (tag + ".exr")), str(tmp_path / (tag + ".png"))
+        r = subprocess.run([exe, spec.config_path, "--spp", "7", "--save-every", "3", "--out", out, "--preview", png, "--seed", "5"] + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **env))
+        log = r.stdout.decode()
+        assert r.returncode == 0, log
+        assert "3 spp saved" in log and "6 spp saved" in log and ("on 3 GPUs" if tag == "three" else "on 1 GPU,") in log, log
+        assert np.array_equal(bits(api.load_exr(out)), bits(want))
+        assert np.array_equal(api.load_image_rgb8(png), shown[..., :3])
+        assert not os.path.exists(out + ".part") and not os.path.exists(png + ".part")
+    r = subprocess.run([exe, spec.config_path, "--devices", "0,x"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 2 and b"bad --devices" in r.stdout
+    r = subprocess.run([exe, spec.config_path, "--devices", "0,0", "--spp", "1", "--out", str(tmp_path / "dup.exr")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       env={k: v for k, v in os.environ.items() if k != "ADYPT_MULTI_SHARED_DEVICE"})
+    assert r.returncode == 1 and b"device listed twice" in r.stdout
+
+
 @pytest.mark.parametrize("viewer", [0, 1, 2, 4, 5])
 def test_display_transform_matches_oracle(viewer, scene_cache, sobol_matrices):
     """adypt_read_display = shaders/screen.glsl over the result image (f4): every byte equals the oracle's."""
