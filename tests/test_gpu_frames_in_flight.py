@@ -125,3 +125,19 @@ def test_lookahead_work_counters_match_after_full_hand_out(scene_cache, sobol_ma
     st = p.GetStats()
     assert (st["rays"], st["nodes_visited"], st["tris_tested"], st["shaded"]) == (ost["rays"], ost["nodes"], ost["tris"], ost["shaded"])
     assert np.array_equal(bits(p.ReadResult()), bits(state.accum[..., :3]))
+
+
+def test_long_progressive_run_is_bit_exact(scene_cache, sobol_matrices):
+    """BASELINE config 5 in miniature: > 1024 samples accumulated progressively.  Far along the Sobol sequence (gray-code bit 10, every
+    direction-number row of the table in use), the sub-pixel index has wrapped around its 8 x 8 grid (spp / tmpLifetime >= 64), and the
+    running mean (out * spp + r) / (spp + 1) has been applied 1100 times in fp32: still every bit equal to the oracle's."""
+    inst = _instance(scene_cache, "tiny0", 24, 16, {"tmpLifetime": 16, "maxBounce": 3, "subpixel": 8}, seed=8)
+    p, c = inst.m_path_tracer, inst.m_config.c
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    state = O.PathTracerState(c.width, c.height)
+    shift = O.shift_bytes(8, c.width, c.height)
+    for n in (500, 1, 599):
+        p.Trace(True, n)
+        O.pt_frames(osc, P, shift, sobol_matrices, state, n)
+        assert np.array_equal(bits(p.ReadResult()), bits(state.accum[..., :3])), "after %d samples" % p.GetSPP()
+    assert p.GetSPP() == 1100
