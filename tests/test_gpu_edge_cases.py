@@ -317,3 +317,45 @@ def test_subpixel_upper_bound():
         pt.SetConfig(p)
     p.subpixel = 46340
     pt.SetConfig(p)
+
+
+def _write_tga(path, img):
+    """uncompressed 24-bit TGA, top-left origin (one of the formats stb_image — and this loader — reads)"""
+    h, w, _ = img.shape
+    hdr = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, w & 255, w >> 8, h & 255, h >> 8, 24, 0x20])
+    with open(path, "wb") as f:
+        f.write(hdr + np.ascontiguousarray(img[..., ::-1]).tobytes())
+
+
+@pytest.mark.parametrize("tw,th", [(1, 1), (3, 5), (64, 64), (257, 2)])
+def test_texture_sampling_edges_match_oracle(tw, th, tmp_path, sobol_matrices):
+    """FetchInfo's bilinear RGB8 fetch with GL_REPEAT (pathtracer.glsl:88-96; OglScene.cpp:33-38) at its awkward inputs: a 1 x 1 texture,
+    sizes that are not powers of two, texture coordinates far outside [0, 1] and negative (the wrap of the texel index and of its
+    right / upper neighbour), and texel centres hit exactly.  Viewer type 0 shows the fetched colour directly; the path-traced frames
+    then use it as Kd."""
+    rs = np.random.RandomState(tw * 131 + th)
+    _write_tga(str(tmp_path / "t.tga"), rs.randint(0, 256, size=(th, tw, 3)).astype(np.uint8))
+    (tmp_path / "q.mtl").write_text("newmtl tex\nKd 1 1 1\nillum 1\nmap_Kd t.tga\nnewmtl lamp\nKd 0 0 0\nKe 6 5 4\nillum 1\n")
+    # a floor quad whose texture coordinates run from -3.25 to 4.5 (and exact multiples of 1 / size along one edge), a lamp above it
+    (tmp_path / "q.obj").write_text(
+        "mtllib q.mtl\nv 0 0 0\nv 10 0 0\nv 10 0 10\nv 0 0 10\nv 2 6 2\nv 8 6 2\nv 8 6 8\nv 2 6 8\n"
+        "vt -3.25 -1.5\nvt 4.5 -1.5\nvt 4.5 2.0\nvt -3.25 2.0\nvn 0 1 0\nvn 0 -1 0\n"
+        "usemtl tex\nf 1/1/1 3/3/1 2/2/1\nf 1/1/1 4/4/1 3/3/1\nusemtl lamp\nf 5//2 6//2 7//2\nf 5//2 7//2 8//2\n")
+    w, h = 61, 47
+    sc, b, pt, p = _tracer(str(tmp_path / "q.obj"), w, h)
+    assert len(sc.textures) == 1 and sc.textures[0].shape == (th, tw, 3) and not sc.warnings
+    osc = O.Scene(b.nodes, b.tri_indices, sc.triangles, sc.materials, textures=sc.textures)
+    ip, iv = api.camera_matrices(70.0, 0.0, -40.0, w, h)
+    pos = [5.0, 5.0, 12.0]
+    pt.SetCamera(ip, iv, pos)
+    P = O.make_params(w, h, pos, ip, iv, stack_size=p.stack_size, max_bounce=p.max_bounce, subpixel=p.subpixel,
+                      tmp_life=p.tmp_lifetime, tmin=p.ray_tmin, clamp=p.clamp, sun=list(p.sun))
+    pt.Trace(False)                                                          # viewer type 0: the diffuse colour FetchInfo returns
+    rgba, _, _ = O.primary_frame(osc, P, 0)
+    got = pt.ReadResult()
+    assert np.array_equal(bits(got), bits(rgba[..., :3]))
+    assert len(np.unique(got.reshape(-1, 3), axis=0)) > (1 if tw * th == 1 else 50)   # the floor really shows the texture
+    pt.Trace(True, 5)
+    st = O.PathTracerState(w, h)
+    O.pt_frames(osc, P, O.shift_bytes(77, w, h), sobol_matrices, st, 5)
+    assert np.array_equal(bits(pt.ReadResult()), bits(st.accum[..., :3]))
