@@ -359,3 +359,54 @@ def test_texture_sampling_edges_match_oracle(tw, th, tmp_path, sobol_matrices):
     st = O.PathTracerState(w, h)
     O.pt_frames(osc, P, O.shift_bytes(77, w, h), sobol_matrices, st, 5)
     assert np.array_equal(bits(pt.ReadResult()), bits(st.accum[..., :3]))
+
+
+def test_material_zoo_matches_oracle(tmp_path, sobol_matrices):
+    """Every branch of Render's illum switch (pathtracer.glsl:144-201) on the device: diffuse, glossy above and AT the e = Ns * 0.01 > 0.3
+    threshold (falls through to diffuse), very sharp lobes, mirrors, dielectrics with Ni below / at / above 1, the values the switch does
+    not name (0, 8, 9: the ray goes straight on), materials without illum (tinyobj default 0), emitters — as patches of one floor under
+    a lamp, with a second layer below so that pass-through and refracted paths keep going."""
+    mats = [("m0", "Kd 0.8 0.7 0.6\nillum 1"), ("m1", "Kd 0.5 0.5 0.5\nKs 0.4 0.4 0.4\nNs 200\nillum 2"), ("m2", "Kd 0.6 0.2 0.2\nKs 0.3 0.3 0.3\nNs 30\nillum 2"),
+            ("m3", "Kd 0.2 0.6 0.2\nKs 0.5 0.5 0.5\nNs 31\nillum 2"), ("m4", "Kd 0.1 0.1 0.1\nKs 0.9 0.9 0.9\nNs 100000\nillum 2"), ("m5", "Ks 0.9 0.8 0.7\nillum 3"),
+            ("m6", "Ks 1.5 1.5 1.5\nillum 4"), ("m7", "Ks 0.3 0.3 0.9\nillum 5"), ("m8", "Kd 1 1 1\nNi 1.5\nillum 6"), ("m9", "Kd 1 1 1\nNi 0.7\nillum 7"),
+            ("m10", "Kd 1 1 1\nNi 1.0\nillum 7"), ("m11", "Kd 1 1 1\nNi 2.4\nillum 7"), ("m12", "Kd 0.9 0.1 0.1\nillum 0"), ("m13", "Kd 0.1 0.9 0.1\nillum 8"),
+            ("m14", "Kd 0.1 0.1 0.9\nillum 9"), ("m15", "Kd 0.3 0.3 0.3"), ("m16", "Kd 0.2 0.2 0.2\nKe 2 3 4\nillum 1"), ("m17", "Kd 0.4 0.4 0.4\nKs 0.2 0.2 0.2\nNs 0\nillum 2")]
+    (tmp_path / "zoo.mtl").write_text("".join("newmtl %s\n%s\n" % m for m in mats) + "newmtl lamp\nKd 0 0 0\nKe 9 8 7\nillum 1\nnewmtl base\nKd 0.7 0.7 0.7\nillum 1\n")
+    v, f = [], []
+    def quad(x0, z0, x1, z1, y, mat, up=True):
+        i = len(v) + 1
+        v.extend([(x0, y, z0), (x1, y, z0), (x1, y, z1), (x0, y, z1)])
+        f.append("usemtl %s\nf %d %d %d\nf %d %d %d\n" % ((mat, i, i + 2, i + 1, i, i + 3, i + 2) if up else (mat, i, i + 1, i + 2, i, i + 2, i + 3)))
+    for k, (name, _) in enumerate(mats):
+        quad(2.0 * (k % 6), 2.0 * (k // 6), 2.0 * (k % 6) + 1.9, 2.0 * (k // 6) + 1.9, 1.0, name)
+    quad(-2, -2, 14, 8, 0.0, "base")                 # below the patches: what pass-through / refracted paths reach
+    quad(1, 1, 11, 5, 5.0, "lamp", up=False)         # the lamp faces down
+    (tmp_path / "zoo.obj").write_text("mtllib zoo.mtl\n" + "".join("v %g %g %g\n" % p for p in v) + "".join(f))
+    w, h = 96, 54
+    sc, b, pt, p = _tracer(str(tmp_path / "zoo.obj"), w, h)
+    p.max_bounce = 7
+    pt.SetConfig(p)
+    osc = O.Scene(b.nodes, b.tri_indices, sc.triangles, sc.materials)
+    ip, iv = api.camera_matrices(75.0, 0.0, -55.0, w, h)
+    pos = [6.0, 4.5, 8.5]
+    pt.SetCamera(ip, iv, pos)
+    P = O.make_params(w, h, pos, ip, iv, stack_size=p.stack_size, max_bounce=p.max_bounce, subpixel=p.subpixel,
+                      tmp_life=p.tmp_lifetime, tmin=p.ray_tmin, clamp=p.clamp, sun=list(p.sun))
+    for viewer in (0, 1, 2, 4, 5):
+        pt.m_viewer_type = viewer
+        pt.Trace(False)
+        rgba, _, _ = O.primary_frame(osc, P, viewer)
+        assert np.array_equal(bits(pt.ReadResult()), bits(rgba[..., :3])), viewer
+    pt.SetInstrumentation(counters=True)
+    pt.ResetStats()
+    pt.Trace(True, 9)
+    st = O.PathTracerState(w, h)
+    ost = O.pt_frames(osc, P, O.shift_bytes(77, w, h), sobol_matrices, st, 9).as_dict()
+    img = pt.ReadResult()
+    assert np.array_equal(bits(img), bits(st.accum[..., :3]))
+    g = pt.GetStats()
+    assert (g["rays"], g["shaded"], g["bad_materials"]) == (ost["rays"], ost["shaded"], 0)
+    tri, _ = pt.ReadHits()
+    seen = set(np.unique(np.frombuffer(sc.triangles, dtype=np.uint8).reshape(-1, 100)[tri[tri >= 0]][:, 96:100].copy().view(np.int32)))
+    assert len(seen) >= len(mats)                    # the camera really sees every patch
+    assert np.isfinite(img).all()
