@@ -322,3 +322,33 @@ def test_obj_face_index_out_of_range_is_an_error(tmp_path):
         assert "not defined" in api.InstanceConfig.last_error()
     (tmp_path / "ok.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 -1/-1/-1\n")
     assert api.Scene().LoadFromFile(str(tmp_path / "ok.obj"))
+
+
+def _obj_cases():
+    return json.load(open(os.path.join(GOLDEN, "obj_syntax_cases.json")))
+
+
+@pytest.mark.parametrize("name", sorted(_obj_cases()))
+def test_obj_mtl_syntax_corners_load_like_the_reference(name, tmp_path):
+    """Users bring their own assets: relative (negative) indices, every `f` index form, polygons (the reference's tinyobjloader 1.2.0
+    clips ears, it does not fan), vertices without normals (Scene.cpp:117-123 decides by the LAST vertex), CRLF / tabs / comments, groups,
+    faces without or with an unknown material, missing / repeated / several mtllib, odd number spellings, extra vertex components, the
+    corners of the MTL syntax.  Expected bytes: the reference's own Scene::LoadFromFile + OglScene::init_materials (compiled by
+    oracle/Makefile) on the same text, tests/golden/make_golden_obj_syntax.py."""
+    c = _obj_cases()[name]
+    with open(tmp_path / "c.obj", "w", newline="") as f:
+        f.write(c["obj"])
+    if c["mtl"] is not None:
+        with open(tmp_path / "m.mtl", "w", newline="") as f:
+            f.write(c["mtl"])
+    sc = api.Scene()
+    ok = sc.LoadFromFile(str(tmp_path / "c.obj"))
+    if c.get("rejected"):
+        assert not ok
+        return
+    assert ok, N.lib.adypt_host_last_error()
+    assert sc.triangles.tobytes().hex() == c["triangles"]
+    assert sc.materials.tobytes().hex() == c["materials"]
+    if O.have_ref():  # build container: the fixture still is what the reference produces
+        r = O.ref("scene", str(tmp_path / "c.obj"), str(tmp_path / "t.bin"), str(tmp_path / "m.bin"))
+        assert r.returncode == 0 and open(tmp_path / "t.bin", "rb").read().hex() == c["triangles"]
