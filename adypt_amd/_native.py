@@ -88,6 +88,8 @@ _SIGS = {
     "adypt_get_spp": (C.c_int, [C.c_void_p]),
     "adypt_set_frames_in_flight": (C.c_int, [C.c_void_p, C.c_int]),
     "adypt_get_frames_in_flight": (C.c_int, [C.c_void_p]),
+    "adypt_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
+    "adypt_get_pipeline": (C.c_int, [C.c_void_p]),
     "adypt_set_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
     "adypt_get_lookahead_frames": (C.c_int, [C.c_void_p]),
     "adypt_read_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),

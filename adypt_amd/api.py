@@ -375,6 +375,13 @@ class HipPathTracer:
     def GetFramesInFlight(self) -> int:
         return N.lib.adypt_get_frames_in_flight(self._ctx)
 
+    def SetPipeline(self, n_pipes: int) -> None:
+        """Sub-batches per batch, each a chain of kernels on its own HIP stream (adypt_set_pipeline); 1 = serial."""
+        N.check(N.lib.adypt_set_pipeline(self._ctx, n_pipes), self._ctx)
+
+    def GetPipeline(self) -> int:
+        return N.lib.adypt_get_pipeline(self._ctx)
+
     def SetLookahead(self, enabled: bool) -> None:
         """One Trace(true) per call (Instance::Update) at batched throughput: see adypt_set_lookahead."""
         N.check(N.lib.adypt_set_lookahead(self._ctx, 1 if enabled else 0), self._ctx)

@@ -196,13 +196,20 @@ int multi_comm_init(adypt_multi *m)
 	std::vector<ncclComm_t> comms((size_t)n, nullptr);
 	ncclResult_t r = api->CommInitAll(comms.data(), n, m->devices.data()); // rank i lives on devices[i]
 	if(r != ncclSuccess) return mfail(m, ADYPT_E_HIP, std::string("ncclCommInitAll: ") + api->GetErrorString(r));
+	// every communicator is parked in its context FIRST (the context then owns and frees it, whatever happens next): a failure of
+	// finish_comm for rank i must not leave the communicators of ranks i+1.. behind, and a retry must not create a second set
+	std::vector<Comm *> parked((size_t)n, nullptr);
 	for(int i = 0; i < n; ++i)
 	{
 		Comm *k = new Comm();
 		k->api = api; k->comm = comms[(size_t)i];
 		park_comm(m->ctx[(size_t)i], k);
-		int rr = finish_comm(m->ctx[(size_t)i], k);
-		if(rr != ADYPT_OK) return mfail_ctx(m, rr, m->ctx[(size_t)i]);
+		parked[(size_t)i] = k;
+	}
+	for(int i = 0; i < n; ++i)
+	{
+		int rr = finish_comm(m->ctx[(size_t)i], parked[(size_t)i]);
+		if(rr != ADYPT_OK) return mfail_ctx(m, rr, m->ctx[(size_t)i]); // a later call starts over: park_comm frees what is parked now
 	}
 	m->comms_ready = true;
 	return ADYPT_OK;

@@ -70,9 +70,11 @@ struct FrameArgs {
 	float4 *done;                  // device: [frame in batch][local pixel] finished sample radiance (batches of > 1 frame only)
 	int32_t width, height;
 	int32_t spp, subpixel, tmp_life, max_bounce; // spp = index of the FIRST frame of the batch
-	int32_t n_frames;              // frames in flight in this pass (path index = frame ordinal * n_local_px + local pixel)
-	int32_t frame_first, frame_stride; // batch frame of ordinal r = frame_first + r * frame_stride (main pass: 0, 1; the
-	                               //   primary-only pass runs just the re-tracing frames of the batch: first one, tmp_life)
+	int32_t n_frames;              // frames of this pass (queue position = frame ordinal * n_local_px + local pixel)
+	int32_t frame_first, frame_stride; // batch frame of ordinal r = frame_first + r * frame_stride (a sub-batch of the main pass:
+	                               //   its first frame, 1; the primary-only pass runs just the re-tracing frames: first one, tmp_life)
+	int32_t batched;               // the pass belongs to a batch of several frames: path id = batch frame * n_local_px + local pixel,
+	                               //   finished samples are parked in done[path id] and applied in frame order by k_resolve
 	int32_t n_local_px;            // owned blocks * 1024
 	int32_t blocks_x;              // image width in 32-px blocks
 	int32_t rank, nranks;
@@ -117,6 +119,12 @@ struct PixelArgs {
 	DeviceStats *stats;
 };
 
+// Keeps VGPRs allocated beyond the kernel's highest register (the clobber makes `reg`, the first one of the next granule of 8,
+// count as used).  Precaution
+// that goes with the append_slot note below: the misbehaving build of k_gen_primary had exactly 16 VGPRs, the same instructions with
+// 24 allocated did not misbehave.  tools/check_vgpr.py fails the build when a kernel's count lands on a multiple of 8 without it.
+#define ADYPT_VGPR_SLACK(reg) asm volatile("; one spare VGPR granule" ::: reg)
+
 __device__ __forceinline__ bool local_pixel_xy(const FrameArgs &f, const int32_t *local_blocks, int L, int *x, int *y)
 {
 	const int blk = local_blocks[L >> 10];
@@ -153,13 +161,22 @@ __device__ __forceinline__ F3 camera_dir(const FrameArgs &f, int px, int py, flo
 }
 
 // Workgroup-level stream compaction into the workgroup's queue segment: returns this thread's output slot (valid
-// only if `alive`).  Wave vote (__ballot / __popcll) -> scan of the 4 wave counts -> ONE device atomic per workgroup.
+// only if `alive`).  Wave vote (__ballot) -> scan of the 4 wave counts -> ONE device atomic per workgroup -> rank of the lane
+// among its wave's survivors (v_mbcnt).
+// The vote is taken AGAIN after the barriers for the rank instead of keeping the first mask alive across them.  Round 3: with the
+// mask held in an SGPR pair over the two s_barriers and the rank computed as popcount(mask & ((1 << lane) - 1)), whole waves of
+// k_gen_primary occasionally (a few workgroups per launch, depending on timing) saw rank 0 in every lane and wrote all their paths
+// to the wave's first slot — in a build whose ISA reads correctly and only when the kernel's VGPR count came out as exactly 16; any
+// perturbation of the code hid it (tools/debug notes in DESIGN.md §10).  The second vote costs one v_cmp and is immune to whatever
+// that was; v_mbcnt is also two instructions instead of the shift / select / popcount five.
 __device__ __forceinline__ uint32_t append_slot(bool alive, uint32_t *seg_counter, uint32_t seg_base)
 {
 	__shared__ uint32_t wave_base[kShadeThreads / 64];
-	const unsigned long long mask = __ballot(alive);
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	if(lane == 0) wave_base[wave] = (uint32_t)__popcll(mask);
+	{
+		const unsigned long long mask = __ballot(alive);
+		if(lane == 0) wave_base[wave] = (uint32_t)__popcll(mask);
+	}
 	__syncthreads();
 	if(threadIdx.x == 0)
 	{
@@ -171,7 +188,8 @@ __device__ __forceinline__ uint32_t append_slot(bool alive, uint32_t *seg_counte
 		for(int w = 0; w < kShadeThreads / 64; ++w) { wave_base[w] = base; base += c[w]; }
 	}
 	__syncthreads();
-	return seg_base + wave_base[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+	const unsigned long long mask = __ballot(alive);
+	return seg_base + wave_base[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 // use_cache: the frame reuses the cached primary hit (spp % tmpLife != 0, pathtracer.glsl:115-120) — the hit
@@ -179,6 +197,7 @@ __device__ __forceinline__ uint32_t append_slot(bool alive, uint32_t *seg_counte
 // bias_mode 0: Camera() of primaryray.glsl (no sub-pixel bias); 1: Camera(SubPixel()) of pathtracer.glsl
 __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int use_cache, int bias_mode)
 {
+	ADYPT_VGPR_SLACK("v16");
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	// each segment takes a contiguous run of local pixels (= whole 32x32 blocks of the image): XCD-local coherence
 	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
@@ -199,7 +218,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, Scen
 	if(!alive) return;
 	const F3 d = camera_dir(f, x, y, bx, by);
 	q.out_o[slot] = make_float4(f.origin[0], f.origin[1], f.origin[2], f.tmin);
-	q.out_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float((int)pi));
+	q.out_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(frame * f.n_local_px + L)); // path id (batch frame, local pixel)
 	q.out_col[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
 	if(use_cache) q.hit[slot] = cache_of_group(f, px, frame_group(f, frame))[L];
 }
@@ -214,9 +233,9 @@ __global__ __launch_bounds__(kShadeThreads) void k_store_cache(FrameArgs f, Queu
 	if(local >= q.count_in[seg * kCursorStride]) return;
 	const uint32_t slot = seg * q.seg_cap + local;
 	const float4 h = q.hit[slot];
-	const uint32_t pi = (uint32_t)__float_as_int(q.ray_d[slot].w); // primary pass: ordinal of the re-tracing frame, local pixel
-	const int ordinal = (int)(pi / (uint32_t)f.n_local_px), L = (int)(pi % (uint32_t)f.n_local_px);
-	cache_of_group(f, px, frame_group(f, f.frame_first + ordinal * f.frame_stride))[L] = make_float4(h.x, h.y, h.z, 0.0f);
+	const uint32_t pi = (uint32_t)__float_as_int(q.ray_d[slot].w); // path id: (batch frame, local pixel)
+	const int frame = (int)(pi / (uint32_t)f.n_local_px), L = (int)(pi % (uint32_t)f.n_local_px);
+	cache_of_group(f, px, frame_group(f, frame))[L] = make_float4(h.x, h.y, h.z, 0.0f);
 }
 
 // Applies finished samples of a batch to the running mean in frame order (pathtracer.glsl:224-226): batch frames
@@ -321,7 +340,7 @@ __device__ inline F3 align_direction(F3 dir, F3 target)
 __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs &px, int pi, int L, F3 ret)
 {
 	const F3 r = f3(gl_min(ret.x, f.clamp), gl_min(ret.y, f.clamp), gl_min(ret.z, f.clamp));
-	if(f.n_frames > 1) { f.done[pi] = make_float4(r.x, r.y, r.z, 1.0f); return; } // applied in frame order by k_resolve (the
+	if(f.batched) { f.done[pi] = make_float4(r.x, r.y, r.z, 1.0f); return; }      // applied in frame order by k_resolve (the
 	                                                                               // slot doubles as the parked radiance of a live path)
 	const float4 old = px.accum[L];
 	const float fs = (float)f.spp, fs1 = (float)(f.spp + 1);
@@ -330,7 +349,10 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 
 // One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for every live path.
 // store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
-__global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, ShadowArgs sh, int b, int store_cache, int count_stats)
+// WAVES = waves per SIMD the register budget is set for: 7 (72 VGPRs) is the fastest when the kernel has the GPU to itself; 8 (64
+// VGPRs, a few spills) lets two workgroups instead of one sit next to a running traversal launch of another pipe.
+template <int WAVES>
+__global__ __launch_bounds__(kShadeThreads, WAVES) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, ShadowArgs sh, int b, int store_cache, int count_stats)
 {
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	const uint32_t n_in = q.count_in[seg * kCursorStride];
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneAr
 		dir = f3(rd.x, rd.y, rd.z);
 		pi = __float_as_int(rd.w);
 		L = pi;
-		if(f.n_frames > 1)
+		if(f.batched)
 		{
 			const int frame = (int)((uint32_t)pi / (uint32_t)f.n_local_px);
 			L = pi - frame * f.n_local_px;
@@ -508,7 +530,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shadow_resolve(FrameArgs f, Q
 	const float4 c4 = sh.col[slot];
 	const int pi = __float_as_int(sh.d[slot].w);
 	int L = pi;
-	if(f.n_frames > 1) L = pi - (int)((uint32_t)pi / (uint32_t)f.n_local_px) * f.n_local_px;
+	if(f.batched) L = pi - (int)((uint32_t)pi / (uint32_t)f.n_local_px) * f.n_local_px;
 	F3 ret = f3(0, 0, 0);
 	if(c4.w != 0.0f) { const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); }
 	if(__float_as_int(sh.hit[slot].x) == -1) ret = fma3(f3(c4.x, c4.y, c4.z), f3(f.sun[0], f.sun[1], f.sun[2]), ret);
@@ -518,6 +540,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shadow_resolve(FrameArgs f, Q
 // primaryray.glsl main (:46-94): colour the primary hit by viewer type; also records the hit in the cache image
 __global__ __launch_bounds__(kShadeThreads) void k_viewer(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int viewer_type)
 {
+	ADYPT_VGPR_SLACK("v32");
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	const uint32_t n_in = q.count_in[seg * kCursorStride];
 	const uint32_t local = chunk * kShadeThreads + threadIdx.x;

@@ -2,8 +2,13 @@
 // wavefront path tracer on one HIP stream.  Replaces OglScene + OglPathTracer (src/Tracer/*.cpp) of the reference.
 //
 // Per frame (= one OglPathTracer::Trace(true), OglPathTracer.cpp:34-61):
-//     memset counters -> k_gen_primary -> [ k_trace -> k_shade ] x maxBounce      (all on ctx->stream, no host sync;
-//     queue sizes live in device memory, the traversal kernel is persistent, the shade grid covers the worst case)
+//     memset counters -> k_gen_primary -> [ k_trace -> k_shade ] x maxBounce      (no host sync; queue sizes live in
+//     device memory, the traversal kernel is persistent, the shade grid covers the worst case)
+// A batch of several frames is cut into sub-batches ("pipes"), each the chain above on its OWN HIP stream over its own window
+// of the ray queues: while one pipe's traversal launch drains (its last, longest rays) or its shade kernel streams the queues
+// through HBM, the other pipe's traversal keeps the vector ALUs busy.  The reference has no barrier between bounces at all
+// (one dispatch runs the whole for(b < uMaxBounce) loop, shaders/pathtracer.glsl:107); results do not depend on any of this:
+// per-path work is independent of queue order and k_resolve applies the finished samples in frame order.
 // There is no CPU fallback anywhere in this file: without a HIP device adypt_create fails with ADYPT_E_NO_DEVICE.
 #include "traverse.hpp"
 #include "ctx_access.hpp"
@@ -23,6 +28,8 @@ namespace {
 
 constexpr int kMaxBounce = 32;
 constexpr int kMaxFramesInFlight = 128;
+constexpr int kMaxPipes = 4;           // sub-batches of a batch that run as concurrent chains (adypt_set_pipeline)
+constexpr int kDefaultPipes = 2;
 
 struct FrameCounters {                 // one memset per frame; every counter on its own 128-byte line
 	uint32_t count[kMaxBounce + 1][kNumSegments * kCursorStride];   // live rays per queue segment after bounce b
@@ -34,6 +41,22 @@ struct FrameCounters {                 // one memset per frame; every counter on
 thread_local std::string g_create_error;
 
 struct EventPair { hipEvent_t a, b; int kind; };
+
+// Zeroes the counters of `n` pipes.  A kernel of the context's stream rather than hipMemsetAsync: a fill of PART of an allocation was
+// observed not to be ordered against the kernels around it on this runtime (their pointers travel inside by-value structs, which
+// the runtime's dependency tracking cannot see) — round 3: cache images and counters read before / cleared after their time.
+__global__ void k_clear_counters(uint4 *p, uint32_t n16) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if(i < n16) p[i] = make_uint4(0, 0, 0, 0); }
+
+// One sub-batch chain of a pipelined batch.  Pipe 0 runs on the context's stream.
+struct Pipe {
+	hipStream_t stream = nullptr;
+	hipEvent_t done = nullptr;         // end of the pipe's chain; the context's stream waits for it before k_resolve
+	FrameCounters *counters = nullptr;
+	uint2 *spill = nullptr;            // traversal stack spill of this pipe's launches (two pipes' launches overlap)
+};
+
+// The part of the ray queues a pass works in: slots [offset, offset + kNumSegments * seg_cap)
+struct QueueWindow { size_t offset; uint32_t seg_cap; };
 
 }  // namespace
 
@@ -62,6 +85,10 @@ struct adypt_ctx {
 	// wavefront queues
 	int64_t capacity = 0;      // queue slots = kNumSegments * seg_cap
 	uint32_t seg_cap = 0;      // slots per XCD-affine segment (multiple of kShadeThreads)
+	size_t alloc_slots = 0;    // allocated slots (>= capacity: the windows of a pipelined batch round up separately)
+	int pipeline = kDefaultPipes; // sub-batches per batch (adypt_set_pipeline); 1 = one chain on the context's stream
+	Pipe pipes[kMaxPipes];
+	hipEvent_t fork_ev = nullptr;
 	float4 *q_o[2] = {nullptr, nullptr}, *q_d[2] = {nullptr, nullptr}, *q_col[2] = {nullptr, nullptr};
 	float4 *d_hit = nullptr;
 	float4 *sh_o = nullptr, *sh_d = nullptr, *sh_col = nullptr, *sh_hit = nullptr; // sun-visibility queue (allocated when enabled)
@@ -79,14 +106,16 @@ struct adypt_ctx {
 	bool queues_ok = false;    // false after a failed (re)allocation of the queues: trace calls return ADYPT_E_STATE
 	uint32_t *d_display = nullptr; // adypt_read_display: one RGBA8 word per local pixel (allocated on first use)
 	RayStats *d_ray_stats = nullptr;
-	FrameCounters *d_counters = nullptr;
+	FrameCounters *d_counters = nullptr; // [kMaxPipes]; pipe k uses d_counters + k
 	DeviceStats *d_stats = nullptr;
-	uint2 *d_spill = nullptr;
+	uint2 *d_spill = nullptr;  // [kMaxPipes][stack_size - lds_depth][total lanes]
 	size_t spill_bytes = 0;
+	size_t lds_bytes = 0;      // dynamic LDS of a traversal launch (>= the stack's: padded when it has to cap the workgroups per CU)
 
 	// launch geometry of the persistent traversal kernel
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0, occupancy_api = 0;
 	uint32_t refill_min = kRefillMin, chunk = kChunk;
+	int shade_waves = 7;       // register budget variant of k_shade (tuning: ADYPT_SHADE_WAVES = 7 | 8)
 
 	// state
 	adypt_pt_params params{}, pending{};
@@ -190,7 +219,7 @@ bool validate_bvh(const adypt_scene_desc &d, std::string *why)
 	return true;
 }
 
-hipEvent_t *begin_timing(adypt_ctx *c, int kind)
+hipEvent_t *begin_timing(adypt_ctx *c, int kind, hipStream_t stream)
 {
 	if(!(c->instrumentation & 1)) return nullptr;
 	EventPair p;
@@ -198,10 +227,10 @@ hipEvent_t *begin_timing(adypt_ctx *c, int kind)
 	else { if(hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr; }
 	p.kind = kind;
 	c->events.push_back(p);
-	(void)hipEventRecord(c->events.back().a, c->stream);
+	(void)hipEventRecord(c->events.back().a, stream);
 	return &c->events.back().b;
 }
-inline void end_timing(adypt_ctx *c, hipEvent_t *stop) { if(stop) (void)hipEventRecord(*stop, c->stream); }
+inline void end_timing(hipEvent_t *stop, hipStream_t stream) { if(stop) (void)hipEventRecord(*stop, stream); }
 
 void harvest_events(adypt_ctx *c)
 {
@@ -214,16 +243,28 @@ void harvest_events(adypt_ctx *c)
 	c->events.clear();
 }
 
+void clear_counters(adypt_ctx *c, FrameCounters *first, int n, hipStream_t stream)
+{
+	static_assert(sizeof(FrameCounters) % 16 == 0, "FrameCounters is cleared 16 bytes at a time");
+	const uint32_t n16 = (uint32_t)(sizeof(FrameCounters) / 16) * (uint32_t)n;
+	hipLaunchKernelGGL(k_clear_counters, dim3((n16 + 255) / 256), dim3(256), 0, stream, (uint4 *)first, n16);
+}
+
 int ensure_spill(adypt_ctx *c, int stack_size)
 {
 	const int extra = stack_size - c->lds_depth;
 	if(extra <= 0) return ADYPT_OK;
-	const size_t need = (size_t)extra * (size_t)c->trace_blocks * kTraceThreads * sizeof(uint2);
-	if(need <= c->spill_bytes) return ADYPT_OK;
-	if(c->d_spill) (void)hipFree(c->d_spill);
-	c->d_spill = nullptr; c->spill_bytes = 0;
-	HIP_TRY(c, hipMalloc((void **)&c->d_spill, need));
-	c->spill_bytes = need;
+	const size_t per_pipe = (size_t)extra * (size_t)c->trace_blocks * kTraceThreads;
+	const size_t need = per_pipe * kMaxPipes * sizeof(uint2);
+	if(need > c->spill_bytes)
+	{
+		HIP_TRY(c, hipDeviceSynchronize()); // launches of any pipe may still be using the old array
+		if(c->d_spill) (void)hipFree(c->d_spill);
+		c->d_spill = nullptr; c->spill_bytes = 0;
+		HIP_TRY(c, hipMalloc((void **)&c->d_spill, need));
+		c->spill_bytes = need;
+	}
+	for(int k = 0; k < kMaxPipes; ++k) c->pipes[k].spill = c->d_spill + (size_t)k * per_pipe;
 	return ADYPT_OK;
 }
 
@@ -233,42 +274,50 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	c->lds_depth = std::max(1, std::min(stack_size, kLdsStackMax));
 	// testing / tuning hook: a smaller LDS part pushes stack entries into the global spill array (tests cover that path)
 	if(const char *ov = getenv("ADYPT_LDS_STACK_DEPTH")) c->lds_depth = std::max(1, std::min(c->lds_depth, atoi(ov)));
-	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
+	size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
 	int per_cu = 0;
 	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
 	c->occupancy_api = per_cu;
 	per_cu = std::max(1, std::min(per_cu, 8));
-	if(const char *ov = getenv("ADYPT_TRACE_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(16, atoi(ov))); // tuning override
+	if(const char *ov = getenv("ADYPT_TRACE_BLOCKS_PER_CU")) // tuning override
+	{
+		const int want = std::max(1, std::min(16, atoi(ov)));
+		// Fewer workgroups per CU than the registers allow: the traversal launches of two pipes overlap, and together they would
+		// fill the CU again — so the launch asks for as much LDS as makes `want` workgroups the most that fit in a CU's 160 KB
+		if(want < per_cu) lds = std::max(lds, std::min<size_t>(64 * 1024, (((size_t)160 * 1024 - 2048) / (size_t)want) & ~(size_t)1023));
+		per_cu = want;
+	}
+	c->lds_bytes = lds;
 	c->trace_blocks = c->num_cus * per_cu;
 	return ensure_spill(c, stack_size);
 }
 
-int launch_trace(adypt_ctx *c, int parity, const uint32_t *count, uint32_t *cursor, int stack_size, bool stats, RayStats *ray_stats, bool any_hit = false,
-				 bool shadow_queue = false)
+int launch_trace(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int parity, const uint32_t *count, uint32_t *cursor, int stack_size, bool stats,
+				 RayStats *ray_stats, bool any_hit = false, bool shadow_queue = false)
 {
 	TraceArgs a;
 	a.nodes = (const uint4 *)c->d_nodes;
 	a.woop = (const float4 *)c->d_woop;
 	a.tri_indices = (const int32_t *)c->d_tri_indices;
-	a.ray_o = shadow_queue ? c->sh_o : c->q_o[parity]; a.ray_d = shadow_queue ? c->sh_d : c->q_d[parity];
-	a.hit = shadow_queue ? c->sh_hit : c->d_hit;
+	a.ray_o = (shadow_queue ? c->sh_o : c->q_o[parity]) + win.offset; a.ray_d = (shadow_queue ? c->sh_d : c->q_d[parity]) + win.offset;
+	a.hit = (shadow_queue ? c->sh_hit : c->d_hit) + win.offset;
 	a.ray_stats = ray_stats;
 	a.count = count; a.cursor = cursor;
-	a.spill = c->d_spill;
+	a.spill = pipe.spill;
 	a.stats = c->d_stats;
-	a.seg_cap = c->seg_cap;
+	a.seg_cap = win.seg_cap;
 	a.refill_min = c->refill_min; a.chunk = c->chunk;
 	a.stack_size = stack_size; a.lds_depth = c->lds_depth;
-	const size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
-	hipEvent_t *stop = begin_timing(c, 0);
+	const size_t lds = c->lds_bytes;
+	hipEvent_t *stop = begin_timing(c, 0, pipe.stream);
 	if(any_hit)
 	{
-		if(stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
-		else hipLaunchKernelGGL((k_trace<false, true>), dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
+		if(stats) hipLaunchKernelGGL((k_trace<true, true>), dim3(c->trace_blocks), dim3(kTraceThreads), lds, pipe.stream, a);
+		else hipLaunchKernelGGL((k_trace<false, true>), dim3(c->trace_blocks), dim3(kTraceThreads), lds, pipe.stream, a);
 	}
-	else if(stats) hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
-	else hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, c->stream, a);
-	end_timing(c, stop);
+	else if(stats) hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, pipe.stream, a);
+	else hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_blocks), dim3(kTraceThreads), lds, pipe.stream, a);
+	end_timing(stop, pipe.stream);
 	HIP_TRY(c, hipGetLastError());
 	return ADYPT_OK;
 }
@@ -283,7 +332,7 @@ void fill_frame(const adypt_ctx *c, FrameArgs *f)
 	f->clamp = c->params.clamp;
 	f->width = c->width; f->height = c->height;
 	f->spp = c->spp; f->subpixel = c->params.subpixel; f->tmp_life = c->params.tmp_lifetime; f->max_bounce = c->params.max_bounce;
-	f->sobol = c->d_sobol; f->done = c->d_done; f->n_frames = 1; f->frame_first = 0; f->frame_stride = 1;
+	f->sobol = c->d_sobol; f->done = c->d_done; f->n_frames = 1; f->frame_first = 0; f->frame_stride = 1; f->batched = 0;
 	f->n_local_px = c->n_local_px; f->blocks_x = c->blocks_x; f->rank = c->rank; f->nranks = c->nranks;
 	f->n_tris = (int32_t)c->n_tris; f->n_mats = (int32_t)c->n_mats; f->n_tex = c->n_tex;
 }
@@ -299,24 +348,35 @@ void fill_pixels(const adypt_ctx *c, PixelArgs *p)
 {
 	p->accum = c->d_accum; p->cache = c->d_cache; p->cache_next = c->d_cache_next; p->shift = c->d_shift; p->stats = c->d_stats;
 }
-// paths per queue segment of a pass over `frames` frames (QueueArgs::seg_paths); its kernels run 8 x seg_paths / 256 workgroups.
-// Sizing the grids for the allocated capacity instead cost ~6 ns per empty workgroup: 13 ms per 8-bounce batch at 66 M slots.
-uint32_t pass_seg_paths(const adypt_ctx *c, int frames)
+// slots per segment that `frames` frames of this context's pixels need (multiple of kShadeThreads)
+uint32_t seg_slots_for(const adypt_ctx *c, int frames)
 {
 	const size_t paths = (size_t)std::max(c->n_local_px, 64) * (size_t)std::max(1, frames);
 	const size_t chunks = (paths + kShadeThreads - 1) / kShadeThreads;
-	return (uint32_t)std::min<size_t>(c->seg_cap, ((chunks + kNumSegments - 1) / kNumSegments) * kShadeThreads);
+	return (uint32_t)(((chunks + kNumSegments - 1) / kNumSegments) * kShadeThreads);
+}
+// paths per queue segment of a pass over `frames` frames (QueueArgs::seg_paths); its kernels run 8 x seg_paths / 256 workgroups.
+// Sizing the grids for the allocated capacity instead cost ~6 ns per empty workgroup: 13 ms per 8-bounce batch at 66 M slots.
+uint32_t pass_seg_paths(const adypt_ctx *c, const QueueWindow &win, int frames) { return std::min(win.seg_cap, seg_slots_for(c, frames)); }
+
+inline QueueWindow full_window(const adypt_ctx *c) { return QueueWindow{0, c->seg_cap}; }
+// window of sub-batch k when a batch is cut into n_pipes sub-batches of at most ceil(frames_in_flight / n_pipes) frames
+inline QueueWindow pipe_window(const adypt_ctx *c, int k, int n_pipes)
+{
+	if(n_pipes <= 1) return full_window(c);
+	const uint32_t cap = seg_slots_for(c, (c->frames_in_flight + n_pipes - 1) / n_pipes);
+	return QueueWindow{(size_t)k * (size_t)cap * kNumSegments, cap};
 }
 
-QueueArgs queue_args(adypt_ctx *c, int in, const uint32_t *count_in, uint32_t *count_out, int frames = 0)
+QueueArgs queue_args(adypt_ctx *c, const QueueWindow &win, int in, const uint32_t *count_in, uint32_t *count_out, int frames = 0)
 {
 	QueueArgs q;
-	q.seg_paths = frames > 0 ? pass_seg_paths(c, frames) : c->seg_cap;
-	q.ray_o = c->q_o[in]; q.ray_d = c->q_d[in]; q.col = c->q_col[in];
-	q.hit = c->d_hit;
-	q.out_o = c->q_o[in ^ 1]; q.out_d = c->q_d[in ^ 1]; q.out_col = c->q_col[in ^ 1];
+	q.seg_paths = frames > 0 ? pass_seg_paths(c, win, frames) : win.seg_cap;
+	q.ray_o = c->q_o[in] + win.offset; q.ray_d = c->q_d[in] + win.offset; q.col = c->q_col[in] + win.offset;
+	q.hit = c->d_hit + win.offset;
+	q.out_o = c->q_o[in ^ 1] + win.offset; q.out_d = c->q_d[in ^ 1] + win.offset; q.out_col = c->q_col[in ^ 1] + win.offset;
 	q.count_in = count_in; q.count_out = count_out;
-	q.seg_cap = c->seg_cap;
+	q.seg_cap = win.seg_cap;
 	return q;
 }
 
@@ -367,7 +427,10 @@ int alloc_queues_raw(adypt_ctx *c, int fif)
 	c->seg_cap = (uint32_t)(((chunks + kNumSegments - 1) / kNumSegments) * kShadeThreads);
 	c->capacity = (int64_t)c->seg_cap * kNumSegments;
 	c->frames_in_flight = fif;
-	const size_t nq = (size_t)c->capacity;
+	size_t nq = (size_t)c->capacity;
+	for(int n = 2; n <= kMaxPipes; ++n) // the windows of an n-way split round up one by one
+		nq = std::max(nq, (size_t)n * kNumSegments * (size_t)seg_slots_for(c, (fif + n - 1) / n));
+	c->alloc_slots = nq;
 	for(int i = 0; i < 2; ++i)
 	{
 		HIP_TRY(c, hipMalloc((void **)&c->q_o[i], nq * sizeof(float4)));
@@ -399,7 +462,7 @@ int alloc_queues(adypt_ctx *c, int fif)
 	void *bufs[] = {c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1], c->d_hit, c->d_done};
 	for(void *b : bufs) if(b) (void)hipFree(b);
 	c->q_o[0] = c->q_o[1] = c->q_d[0] = c->q_d[1] = c->q_col[0] = c->q_col[1] = c->d_hit = c->d_done = nullptr;
-	c->capacity = 0; c->seg_cap = 0;
+	c->capacity = 0; c->seg_cap = 0; c->alloc_slots = 0; c->frames_in_flight = previous;
 	c->error = why + " (the context has no ray queues left: destroy it)";
 	return r;
 }
@@ -408,7 +471,7 @@ int ensure_shadow_queue(adypt_ctx *c)
 {
 	if(c->sh_o) return ADYPT_OK;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	const size_t nq = (size_t)c->capacity;
+	const size_t nq = c->alloc_slots;
 	HIP_TRY(c, hipMalloc((void **)&c->sh_o, nq * sizeof(float4)));
 	HIP_TRY(c, hipMalloc((void **)&c->sh_d, nq * sizeof(float4)));
 	HIP_TRY(c, hipMalloc((void **)&c->sh_col, nq * sizeof(float4)));
@@ -459,9 +522,9 @@ int resolve_batch_frames(adypt_ctx *c, const SceneArgs &sc, const PixelArgs &px,
 	FrameArgs f;
 	fill_frame(c, &f);
 	f.spp = c->batch_spp; f.n_frames = c->batch_frames;
-	hipEvent_t *stop = begin_timing(c, 1);
+	hipEvent_t *stop = begin_timing(c, 1, c->stream);
 	hipLaunchKernelGGL(k_resolve, dim3((c->n_local_px + 255) / 256), dim3(256), 0, c->stream, f, sc, px, first, count);
-	end_timing(c, stop);
+	end_timing(stop, c->stream);
 	HIP_TRY(c, hipGetLastError());
 	const int life = std::max(1, c->params.tmp_lifetime);
 	const int group = (c->batch_spp + first + count - 1) / life - c->batch_spp / life;
@@ -547,11 +610,17 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 #define HIP_CREATE(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) { c->error = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? ADYPT_E_OOM : ADYPT_E_HIP); } } while(0)
 	HIP_CREATE(hipSetDevice(c->device));
 	HIP_CREATE(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	c->pipes[0].stream = c->stream;
+	for(int k = 1; k < kMaxPipes; ++k) HIP_CREATE(hipStreamCreateWithFlags(&c->pipes[k].stream, hipStreamNonBlocking));
+	for(int k = 0; k < kMaxPipes; ++k) HIP_CREATE(hipEventCreateWithFlags(&c->pipes[k].done, hipEventDisableTiming));
+	HIP_CREATE(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+	if(const char *ov = getenv("ADYPT_PIPELINE")) c->pipeline = std::max(1, std::min(kMaxPipes, atoi(ov)));
 	hipDeviceProp_t prop;
 	HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
 	c->num_cus = prop.multiProcessorCount;
 	if(const char *ov = getenv("ADYPT_REFILL_MIN")) c->refill_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
+	if(const char *ov = getenv("ADYPT_SHADE_WAVES")) c->shade_waves = atoi(ov) == 8 ? 8 : 7;
 
 	c->n_nodes = d->n_nodes; c->n_refs = d->n_refs; c->n_tris = d->n_tris; c->n_mats = d->n_mats; c->n_tex = d->n_textures;
 	c->width = d->width; c->height = d->height; c->rank = d->tile_rank; c->nranks = d->tile_nranks;
@@ -621,9 +690,10 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		HIP_CREATE(hipHostMalloc((void **)&c->h_sobol[i], (size_t)kMaxFramesInFlight * 64 * sizeof(float), hipHostMallocDefault));
 		HIP_CREATE(hipEventCreateWithFlags(&c->sobol_done[i], hipEventDisableTiming));
 	}
-	HIP_CREATE(hipMalloc((void **)&c->d_counters, sizeof(FrameCounters)));
+	HIP_CREATE(hipMalloc((void **)&c->d_counters, sizeof(FrameCounters) * kMaxPipes));
+	for(int k = 0; k < kMaxPipes; ++k) c->pipes[k].counters = c->d_counters + k;
 	HIP_CREATE(hipMalloc((void **)&c->d_stats, sizeof(DeviceStats)));
-	HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(FrameCounters)));
+	HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(FrameCounters) * kMaxPipes));
 	HIP_CREATE(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
 
 	// defaults of InstanceConfig::PT (src/InstanceConfig.hpp:21-27), seed 0
@@ -643,7 +713,7 @@ void adypt_destroy(adypt_ctx *c)
 {
 	if(!c) return;
 	(void)hipSetDevice(c->device);
-	if(c->stream) (void)hipStreamSynchronize(c->stream);
+	for(int k = 0; k < kMaxPipes; ++k) if(c->pipes[k].stream) (void)hipStreamSynchronize(c->pipes[k].stream);
 	if(c->comm && c->comm_free) c->comm_free(c->comm);
 	c->comm = nullptr;
 	for(EventPair &p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -657,6 +727,12 @@ void adypt_destroy(adypt_ctx *c)
 		if(c->h_sobol[i]) (void)hipHostFree(c->h_sobol[i]);
 		if(c->sobol_done[i]) (void)hipEventDestroy(c->sobol_done[i]);
 	}
+	for(int k = 0; k < kMaxPipes; ++k)
+	{
+		if(c->pipes[k].done) (void)hipEventDestroy(c->pipes[k].done);
+		if(k > 0 && c->pipes[k].stream) (void)hipStreamDestroy(c->pipes[k].stream);
+	}
+	if(c->fork_ev) (void)hipEventDestroy(c->fork_ev);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -756,6 +832,16 @@ int adypt_set_frames_in_flight(adypt_ctx *c, int n)
 
 int adypt_get_frames_in_flight(const adypt_ctx *c) { return c ? c->frames_in_flight : ADYPT_E_INVALID; }
 
+int adypt_set_pipeline(adypt_ctx *c, int n_pipes)
+{
+	if(!c) return ADYPT_E_INVALID;
+	if(n_pipes < 1 || n_pipes > kMaxPipes) return fail(c, ADYPT_E_INVALID, "adypt_set_pipeline: n_pipes must be in [1, " + std::to_string(kMaxPipes) + "]");
+	c->pipeline = n_pipes; // takes effect with the next batch; nothing in flight depends on it
+	return ADYPT_OK;
+}
+
+int adypt_get_pipeline(const adypt_ctx *c) { return c ? c->pipeline : ADYPT_E_INVALID; }
+
 int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 {
 	if(!c) return ADYPT_E_INVALID;
@@ -771,21 +857,24 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	if(c->n_local_px == 0) return ADYPT_OK; // a tile shard that owns no 32x32 block (more ranks than block diagonals): nothing to render
 	FrameArgs f; SceneArgs sc; PixelArgs px;
 	fill_frame(c, &f); fill_scene(c, &sc); fill_pixels(c, &px);
-	HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
-	const int grid_c = (int)(kNumSegments * (pass_seg_paths(c, 1) / kShadeThreads)); // kNumSegments x chunks per segment of a one-frame pass
+	const Pipe &pipe = c->pipes[0];
+	const QueueWindow win = full_window(c);
+	FrameCounters *ctr = pipe.counters;
+	clear_counters(c, ctr, 1, c->stream);
+	const int grid_c = (int)(kNumSegments * (pass_seg_paths(c, win, 1) / kShadeThreads)); // kNumSegments x chunks per segment of a one-frame pass
 	{
-		QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0], 1); // writes queue 0
-		hipEvent_t *stop = begin_timing(c, 1);
+		QueueArgs q = queue_args(c, win, 1, ctr->count[0], ctr->count[0], 1); // writes queue 0
+		hipEvent_t *stop = begin_timing(c, 1, c->stream);
 		hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 0);
-		end_timing(c, stop);
+		end_timing(stop, c->stream);
 	}
-	r = launch_trace(c, 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr);
+	r = launch_trace(c, pipe, win, 0, ctr->count[0], ctr->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr);
 	if(r != ADYPT_OK) return r;
 	{
-		QueueArgs q = queue_args(c, 0, c->d_counters->count[0], c->d_counters->count[1], 1);
-		hipEvent_t *stop = begin_timing(c, 1);
+		QueueArgs q = queue_args(c, win, 0, ctr->count[0], ctr->count[1], 1);
+		hipEvent_t *stop = begin_timing(c, 1, c->stream);
 		hipLaunchKernelGGL(k_viewer, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, viewer_type);
-		end_timing(c, stop);
+		end_timing(stop, c->stream);
 	}
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -887,60 +976,94 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			HIP_TRY(c, hipMemcpyAsync(c->d_sobol, padded, (size_t)m * 64 * sizeof(float), hipMemcpyHostToDevice, c->stream));
 			HIP_TRY(c, hipEventRecord(c->sobol_done[slot], c->stream));
 		}
-		HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
-		int use_cache = (m == 1 && n_retrace) ? 0 : 1;
+		const int use_cache = (m == 1 && n_retrace) ? 0 : 1;
+		f.batched = m > 1 ? 1 : 0;
 		if(m > 1 && n_retrace)
 		{
 			// primary-only pass of the re-tracing frames: camera rays -> traversal -> cache image of each frame's group
+			// (on the context's stream, in the whole queue: every sub-batch below starts from these cache images)
+			const Pipe &pipe = c->pipes[0];
+			const QueueWindow win = full_window(c);
+			FrameCounters *ctr = pipe.counters;
+			clear_counters(c, ctr, 1, c->stream);
 			f.n_frames = n_retrace; f.frame_first = first_retrace; f.frame_stride = life;
-			const int grid_r = (int)(kNumSegments * (pass_seg_paths(c, n_retrace) / kShadeThreads));
-			QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0], n_retrace);
-			hipEvent_t *stop = begin_timing(c, 1);
+			const int grid_r = (int)(kNumSegments * (pass_seg_paths(c, win, n_retrace) / kShadeThreads));
+			QueueArgs q = queue_args(c, win, 1, ctr->count[0], ctr->count[0], n_retrace);
+			hipEvent_t *stop = begin_timing(c, 1, c->stream);
 			hipLaunchKernelGGL(k_gen_primary, dim3(grid_r), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 1);
-			end_timing(c, stop);
-			int r = launch_trace(c, 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, stats, nullptr);
+			end_timing(stop, c->stream);
+			int r = launch_trace(c, pipe, win, 0, ctr->count[0], ctr->cursor[0], c->params.stack_size, stats, nullptr);
 			if(r != ADYPT_OK) return r;
-			QueueArgs q2 = queue_args(c, 0, c->d_counters->count[0], c->d_counters->count[1], n_retrace);
-			stop = begin_timing(c, 1);
+			QueueArgs q2 = queue_args(c, win, 0, ctr->count[0], ctr->count[1], n_retrace);
+			stop = begin_timing(c, 1, c->stream);
 			hipLaunchKernelGGL(k_store_cache, dim3(grid_r), dim3(kShadeThreads), 0, c->stream, f, q2, px);
-			end_timing(c, stop);
-			HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
-			f.frame_first = 0; f.frame_stride = 1;
+			end_timing(stop, c->stream);
+			f.frame_stride = 1;
 		}
-		f.n_frames = m;
-		const int grid_c = (int)(kNumSegments * (pass_seg_paths(c, m) / kShadeThreads)); // kNumSegments x chunks per segment of this batch
+		// The main pass, cut into n_pipes sub-batches of consecutive frames; sub-batch k = the chain gen -> [trace -> shade] x
+		// maxBounce on pipe k's stream in window k of the queues.  Everything before this point (Sobol upload, primary-only
+		// pass, the previous batch's k_resolve) is ordered before every chain by the fork event, every chain before k_resolve.
+		const int n_pipes = m > 1 ? std::max(1, std::min(std::min(c->pipeline, kMaxPipes), m)) : 1;
+		// the counters of all pipes are contiguous: one clearing launch, on the context's stream, before the chains fork
+		clear_counters(c, c->d_counters, n_pipes, c->stream);
+		if(n_pipes > 1)
 		{
-			QueueArgs q = queue_args(c, 1, c->d_counters->count[0], c->d_counters->count[0], m); // out = queue 0
-			hipEvent_t *stop = begin_timing(c, 1);
-			hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, use_cache, 1);
-			end_timing(c, stop);
+			HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
+			for(int k = 1; k < n_pipes; ++k) HIP_TRY(c, hipStreamWaitEvent(c->pipes[k].stream, c->fork_ev, 0));
+		}
+		struct Sub { QueueWindow win; FrameArgs f; int grid; };
+		Sub sub[kMaxPipes];
+		for(int k = 0, frame0 = 0; k < n_pipes; ++k)
+		{
+			const int frames_k = m / n_pipes + (k < m % n_pipes ? 1 : 0);
+			sub[k].win = pipe_window(c, k, n_pipes);
+			sub[k].f = f;
+			sub[k].f.n_frames = frames_k; sub[k].f.frame_first = frame0;
+			sub[k].grid = (int)(kNumSegments * (pass_seg_paths(c, sub[k].win, frames_k) / kShadeThreads)); // kNumSegments x chunks per segment
+			frame0 += frames_k;
+			const Pipe &pipe = c->pipes[k];
+			QueueArgs q = queue_args(c, sub[k].win, 1, pipe.counters->count[0], pipe.counters->count[0], frames_k); // out = queue 0
+			hipEvent_t *stop = begin_timing(c, 1, pipe.stream);
+			hipLaunchKernelGGL(k_gen_primary, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, use_cache, 1);
+			end_timing(stop, pipe.stream);
 		}
 		for(int b = 0; b < max_bounce; ++b)
 		{
 			const int in = b & 1;
-			if(!(b == 0 && use_cache))
+			for(int k = 0; k < n_pipes; ++k) // bounce by bounce over the pipes: their launches reach the GPU interleaved
 			{
-				int r = launch_trace(c, in, c->d_counters->count[b], c->d_counters->cursor[b], c->params.stack_size, stats, nullptr);
-				if(r != ADYPT_OK) return r;
+				const Pipe &pipe = c->pipes[k];
+				FrameCounters *ctr = pipe.counters;
+				if(!(b == 0 && use_cache))
+				{
+					int r = launch_trace(c, pipe, sub[k].win, in, ctr->count[b], ctr->cursor[b], c->params.stack_size, stats, nullptr);
+					if(r != ADYPT_OK) return r;
+				}
+				QueueArgs q = queue_args(c, sub[k].win, in, ctr->count[b], ctr->count[b + 1], sub[k].f.n_frames);
+				ShadowArgs sh;
+				sh.o = c->sh_o + sub[k].win.offset; sh.d = c->sh_d + sub[k].win.offset; sh.col = c->sh_col + sub[k].win.offset; sh.hit = c->sh_hit + sub[k].win.offset;
+				sh.count = ctr->sh_count[b];
+				memcpy(sh.dir, c->sun_dir, sizeof(sh.dir));
+				sh.enabled = c->sun_visibility;
+				hipEvent_t *stop = begin_timing(c, 1, pipe.stream);
+				if(c->shade_waves == 8) hipLaunchKernelGGL(k_shade<8>, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, sh, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
+				else hipLaunchKernelGGL(k_shade<7>, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, sh, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
+				end_timing(stop, pipe.stream);
+				if(c->sun_visibility)
+				{
+					// the escaped paths of this bounce: any-hit query towards the sun, then sun term + accumulate (pathtracer.glsl:130-135)
+					int r = launch_trace(c, pipe, sub[k].win, 0, ctr->sh_count[b], ctr->sh_cursor[b], c->params.stack_size, stats, nullptr, true, true);
+					if(r != ADYPT_OK) return r;
+					stop = begin_timing(c, 1, pipe.stream);
+					hipLaunchKernelGGL(k_shadow_resolve, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, q, px, sh);
+					end_timing(stop, pipe.stream);
+				}
 			}
-			QueueArgs q = queue_args(c, in, c->d_counters->count[b], c->d_counters->count[b + 1], m);
-			ShadowArgs sh;
-			sh.o = c->sh_o; sh.d = c->sh_d; sh.col = c->sh_col; sh.hit = c->sh_hit;
-			sh.count = c->d_counters->sh_count[b];
-			memcpy(sh.dir, c->sun_dir, sizeof(sh.dir));
-			sh.enabled = c->sun_visibility;
-			hipEvent_t *stop = begin_timing(c, 1);
-			hipLaunchKernelGGL(k_shade, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, sh, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
-			end_timing(c, stop);
-			if(c->sun_visibility)
-			{
-				// the escaped paths of this bounce: any-hit query towards the sun, then sun term + accumulate (pathtracer.glsl:130-135)
-				int r = launch_trace(c, 0, c->d_counters->sh_count[b], c->d_counters->sh_cursor[b], c->params.stack_size, stats, nullptr, true, true);
-				if(r != ADYPT_OK) return r;
-				stop = begin_timing(c, 1);
-				hipLaunchKernelGGL(k_shadow_resolve, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, q, px, sh);
-				end_timing(c, stop);
-			}
+		}
+		for(int k = 1; k < n_pipes; ++k)
+		{
+			HIP_TRY(c, hipEventRecord(c->pipes[k].done, c->pipes[k].stream));
+			HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pipes[k].done, 0));
 		}
 		HIP_TRY(c, hipGetLastError());
 		if(m > 1)
@@ -1032,7 +1155,7 @@ static int trace_rays_impl(adypt_ctx *c, const float *rays, int64_t n, adypt_hit
 			d[(size_t)i] = make_float4(r[4], r[5], r[6], 0.0f);
 		}
 		// the batch is cut into kNumSegments consecutive pieces, piece s occupying the head of queue segment s
-		HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, sizeof(FrameCounters), c->stream));
+		clear_counters(c, c->d_counters, 1, c->stream);
 		const int64_t piece = (m + kNumSegments - 1) / kNumSegments; // <= seg_cap because m <= capacity
 		uint32_t counts[kNumSegments * kCursorStride] = {0};
 		if(with_stats) rs.resize((size_t)m);
@@ -1046,7 +1169,7 @@ static int trace_rays_impl(adypt_ctx *c, const float *rays, int64_t n, adypt_hit
 			HIP_TRY(c, hipMemcpyAsync(c->q_d[0] + off, d.data() + b0, (size_t)n_s * sizeof(float4), hipMemcpyHostToDevice, c->stream));
 		}
 		HIP_TRY(c, hipMemcpyAsync(c->d_counters->count[0], counts, sizeof(counts), hipMemcpyHostToDevice, c->stream));
-		int r = launch_trace(c, 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, with_stats != 0, with_stats ? c->d_ray_stats : nullptr, any_hit);
+		int r = launch_trace(c, c->pipes[0], full_window(c), 0, c->d_counters->count[0], c->d_counters->cursor[0], c->params.stack_size, with_stats != 0, with_stats ? c->d_ray_stats : nullptr, any_hit);
 		if(r != ADYPT_OK) return r;
 		for(int s = 0; s < kNumSegments; ++s)
 		{

@@ -22,6 +22,16 @@
 #pragma once
 #include "shade.hpp"
 
+// Measurement hooks: empty in the product.  A measurement-only build (-DADYPT_MEASUREMENT_BUILD -DADYPT_ABLATE_<what>, tools/ab.py)
+// takes their bodies — deliberately redundant loads / instructions that price a pipeline — from csrc/measure/k_trace_ablations.hpp.
+#ifdef ADYPT_MEASUREMENT_BUILD
+#include "../measure/k_trace_ablations.hpp"
+#else
+#define ADYPT_MEASURE_AFTER_TRI_LOADS(w0)
+#define ADYPT_MEASURE_AFTER_NODE_LOADS(np, lane)
+#define ADYPT_MEASURE_AFTER_SLAB_TEST(aox, aoy, aoz, aix, aiy)
+#endif
+
 namespace adypt {
 
 constexpr int kRefillMin = 16; // default: refill when at least this many lanes of the wave are idle (or all are)
@@ -150,13 +160,8 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				dir.x = fabsf(dir.x) > ooeps ? dir.x : (dir.x >= 0 ? ooeps : -ooeps);
 				dir.y = fabsf(dir.y) > ooeps ? dir.y : (dir.y >= 0 ? ooeps : -ooeps);
 				dir.z = fabsf(dir.z) > ooeps ? dir.z : (dir.z >= 0 ? ooeps : -ooeps);
-#ifdef ADYPT_ABLATE_SETUP
-				// measurement-only build: price of the per-lane ray setup (wrong results: no normalisation, approximate reciprocals)
-				idir = f3(__builtin_amdgcn_rcpf(dir.x), __builtin_amdgcn_rcpf(dir.y), __builtin_amdgcn_rcpf(dir.z));
-#else
 				dir = normalize3(dir);
 				idir = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-#endif
 				nx = dir.x < 0; ny = dir.y < 0; nz = dir.z < 0;
 				octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
 				F3 origin = f3(ro.x, ro.y, ro.z);
@@ -269,14 +274,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			{
 				const float4 *w0 = a.woop + (size_t)tri_sel * 3;
 				wp0 = w0[0]; wp1 = w0[1]; wp2 = w0[2];
-#ifdef ADYPT_ABLATE_EXTRA_TRI_LOADS
-				{	// measurement-only build: the triangle loads a second time (L1 hits)
-					const float4 *x0 = w0;
-					asm volatile("" : "+v"(x0));
-					const float4 e0 = x0[0], e1 = x0[1], e2 = x0[2];
-					asm volatile("" :: "v"(e0.x), "v"(e0.w), "v"(e1.x), "v"(e1.w), "v"(e2.x), "v"(e2.w));
-				}
-#endif
+				ADYPT_MEASURE_AFTER_TRI_LOADS(w0);
 			}
 			uint4 n0, n1, n2, n3, n4;
 			ADYPT_DEF4(n0); ADYPT_DEF4(n1); ADYPT_DEF4(n2); ADYPT_DEF4(n3); ADYPT_DEF4(n4);
@@ -288,23 +286,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			{
 				const uint4 *np = a.nodes + (size_t)node * 5;
 				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
-#ifdef ADYPT_ABLATE_EXTRA_LOADS_FEW
-				if((lane & 3) == 0)
-				{	// measurement-only build: the same 5 extra loads, but only from every 4th lane: does the price follow lanes or instructions?
-					const uint4 *np2 = np;
-					asm volatile("" : "+v"(np2));
-					const uint4 e0 = np2[0], e1 = np2[1], e2 = np2[2], e3 = np2[3], e4 = np2[4];
-					asm volatile("" :: "v"(e0.x), "v"(e0.w), "v"(e1.x), "v"(e1.w), "v"(e2.x), "v"(e2.w), "v"(e3.x), "v"(e3.w), "v"(e4.x), "v"(e4.w));
-				}
-#endif
-#ifdef ADYPT_ABLATE_EXTRA_LOADS
-				{	// measurement-only build: issue the same 5 loads a second time (L1 hits) to price the vector-memory issue path
-					const uint4 *np2 = np;
-					asm volatile("" : "+v"(np2)); // launder the pointer so the duplicate loads are not CSE'd
-					const uint4 e0 = np2[0], e1 = np2[1], e2 = np2[2], e3 = np2[3], e4 = np2[4];
-					asm volatile("" :: "v"(e0.x), "v"(e0.w), "v"(e1.x), "v"(e1.w), "v"(e2.x), "v"(e2.w), "v"(e3.x), "v"(e3.w), "v"(e4.x), "v"(e4.w));
-				}
-#endif
+				ADYPT_MEASURE_AFTER_NODE_LOADS(np, lane);
 			}
 			__builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting arithmetic between the load issues
 
@@ -386,15 +368,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 						if(cmin <= cmax) hitmask |= ((child_bits4 >> sh) & 0xffu) << ((bit_index4 >> sh) & 0xffu);
 					}
 				}
-#ifdef ADYPT_ABLATE_EXTRA_VALU
-				{	// measurement-only build: 24 extra independent VALU instructions per slab test (+7 % issued instructions)
-					float e0 = aox, e1 = aoy, e2 = aoz, e3 = aix;
-#pragma unroll
-					for(int k = 0; k < 6; ++k)
-						asm volatile("v_add_f32 %0, %0, %4\nv_add_f32 %1, %1, %4\nv_add_f32 %2, %2, %4\nv_add_f32 %3, %3, %4" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3) : "v"(aiy));
-					asm volatile("" :: "v"(e0), "v"(e1), "v"(e2), "v"(e3));
-				}
-#endif
+				ADYPT_MEASURE_AFTER_SLAB_TEST(aox, aoy, aoz, aix, aiy);
 				ng_y = (hitmask & 0xff000000u) | (head_w >> 24);
 				tg_y = hitmask & 0x00ffffffu;
 			}

@@ -598,7 +598,12 @@ int adypt_load_image_rgb8(const char *path, uint8_t **rgb, int32_t *width, int32
 	if(!path || !rgb || !width || !height) { set_host_error("adypt_load_image_rgb8: null argument"); return ADYPT_E_INVALID; }
 	adypt::TextureImage img;
 	std::string err;
-	if(!adypt::decode_image_rgb8(path, &img, &err)) { set_host_error(std::string(path) + ": " + err); return ADYPT_E_PARSE; }
+	try
+	{
+		if(!adypt::decode_image_rgb8(path, &img, &err)) { set_host_error(std::string(path) + ": " + err); return ADYPT_E_PARSE; }
+	}
+	catch(const std::bad_alloc &) { set_host_error(std::string(path) + ": out of memory while decoding"); return ADYPT_E_OOM; } // nothing may unwind across the C ABI
+	catch(const std::exception &e) { set_host_error(std::string(path) + ": " + e.what()); return ADYPT_E_PARSE; }
 	*rgb = (uint8_t *)malloc(std::max<size_t>(1, img.rgb.size()));
 	if(!*rgb) { set_host_error("out of memory"); return ADYPT_E_OOM; }
 	memcpy(*rgb, img.rgb.data(), img.rgb.size());

@@ -80,7 +80,7 @@ bool decode_bmp(const std::vector<uint8_t> &b, TextureImage *out, std::string *e
 	if(!(paletted || bpp == 24 || bpp == 32) || !(comp == 0 || (comp == 3 && bpp == 32))) { *err = "unsupported BMP variant"; return false; }
 	const bool flip = h > 0;
 	if(h < 0) h = -h;
-	if(w <= 0 || h <= 0) { *err = "bad BMP size"; return false; }
+	if(w <= 0 || h <= 0 || (uint64_t)w * (uint64_t)h > ((uint64_t)1 << 28)) { *err = "bad BMP size"; return false; } // also keeps stride * h below SIZE_MAX
 	std::vector<uint8_t> palette;
 	if(paletted)
 	{
@@ -153,6 +153,7 @@ bool decode_tga(const std::vector<uint8_t> &b, TextureImage *out, std::string *e
 		pos += (size_t)pal_len * eb;
 	}
 	const int bytes = (bpp + 7) / 8;
+	if((uint64_t)w * (uint64_t)h > ((uint64_t)1 << 28)) { *err = "TGA image too large"; return false; } // before anything is allocated
 	std::vector<uint8_t> px((size_t)w * h * bytes);
 	if(!rle)
 	{

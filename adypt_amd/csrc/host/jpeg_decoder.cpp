@@ -194,8 +194,10 @@ bool decode_block_baseline(Decoder &z, int16_t data[64], Component &c)
 	const uint16_t *dq = z.dequant[c.tq];
 	const int t = z.decode(z.huff_dc[c.hd]);
 	if(t < 0 || t > 15) return z.fail("JPEG: bad DC code");
-	c.dc_pred += z.receive_extend(t);
-	data[0] = (int16_t)(c.dc_pred * dq[0]);
+	// (unsigned arithmetic: a corrupt stream may push the prediction out of int range — wraps instead of overflowing; identical
+	// to stb's int arithmetic for every stream whose values fit)
+	c.dc_pred = (int)((uint32_t)c.dc_pred + (uint32_t)z.receive_extend(t));
+	data[0] = (int16_t)((uint32_t)c.dc_pred * (uint32_t)dq[0]);
 	for(int k = 1; k < 64;)
 	{
 		const int rs = z.decode(z.huff_ac[c.ha]);
@@ -226,8 +228,8 @@ bool decode_block_prog_dc(Decoder &z, int16_t data[64], Component &c)
 		memset(data, 0, 64 * sizeof(int16_t));
 		const int t = z.decode(z.huff_dc[c.hd]);
 		if(t < 0 || t > 15) return z.fail("JPEG: bad DC code");
-		c.dc_pred += z.receive_extend(t);
-		data[0] = (int16_t)(c.dc_pred * (1 << z.succ_low));
+		c.dc_pred = (int)((uint32_t)c.dc_pred + (uint32_t)z.receive_extend(t));
+		data[0] = (int16_t)((uint32_t)c.dc_pred * (1u << z.succ_low));
 	}
 	else if(z.bit()) data[0] = (int16_t)(data[0] + (int16_t)(1 << z.succ_low));
 	return true;
@@ -413,6 +415,11 @@ bool process_frame_header(Decoder &z)
 		if(c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) return z.fail("JPEG: bad sampling factors");
 		z.hmax = std::max(z.hmax, c.h); z.vmax = std::max(z.vmax, c.v);
 	}
+	// a sampling factor that does not divide the maximum (e.g. 2x1, 3x1, 1x1) has no integer up-sampling step: the row filters
+	// below would read W / (hmax / h) samples from a row that holds fewer (current stb_image rejects these as "bad H" / "bad V";
+	// the copy vendored by the reference, dep/stb_image.h:2976-2977, does not and reads past its buffer)
+	for(int i = 0; i < z.ncomp; ++i)
+		if(z.hmax % z.comp[i].h != 0 || z.vmax % z.comp[i].v != 0) return z.fail("JPEG: sampling factors do not divide the maximum");
 	z.mcu_x = (z.width + z.hmax * 8 - 1) / (z.hmax * 8);
 	z.mcu_y = (z.height + z.vmax * 8 - 1) / (z.vmax * 8);
 	for(int i = 0; i < z.ncomp; ++i)
@@ -660,7 +667,7 @@ bool decode_jpeg(const std::vector<uint8_t> &bytes, TextureImage *out, std::stri
 		Res &r = res[k];
 		r.hs = z.hmax / z.comp[k].h; r.vs = z.vmax / z.comp[k].v;
 		r.ystep = r.vs >> 1; r.ypos = 0;
-		r.w_lores = (W + r.hs - 1) / r.hs;
+		r.w_lores = std::min((W + r.hs - 1) / r.hs, z.comp[k].w2); // never more samples than a decoded row holds
 		r.line0 = r.line1 = z.comp[k].data.data();
 		r.buf.assign((size_t)W + 3 + 8, 0);
 	}

@@ -119,15 +119,32 @@ def comm_unique_id() -> bytes:
 
 
 def rendezvous_path() -> str:
-    """One file per job: keyed by the launcher's port and run id so concurrent or repeated jobs never read a stale id."""
+    """One file per job, inside a directory only this user can enter (mode 0700, ownership checked): keyed by the launcher's port and
+    run id so concurrent or repeated jobs never read a stale id.  Without a run id the launcher's pid (our parent) stands in for it —
+    ranks of one torch.distributed.run share it; launchers that start every rank from a different parent must set ADYPT_RUN_ID."""
     import os
+    import stat
     import tempfile
-    key = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("ADYPT_RUN_ID", "none")))
-    return os.path.join(os.environ.get("ADYPT_RENDEZVOUS_DIR", tempfile.gettempdir()), "adypt_rccl_id_%s_%d" % (key, os.getppid()))
+    base = os.environ.get("ADYPT_RENDEZVOUS_DIR") or os.path.join(tempfile.gettempdir(), "adypt_rccl_%d" % os.getuid())
+    os.makedirs(base, mode=0o700, exist_ok=True)
+    st = os.lstat(base)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077 and not os.environ.get("ADYPT_RENDEZVOUS_DIR")):
+        raise RuntimeError("rendezvous directory %s is not a private directory of this user" % base)
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("ADYPT_RUN_ID")
+    key = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), run_id if run_id else "ppid%d" % os.getppid())
+    return os.path.join(base, "id_" + "".join(ch if ch.isalnum() or ch in "-_." else "_" for ch in key))
+
+
+def _write_new(path: str, data: bytes) -> None:
+    """Create `path` (it must not exist, symlinks are not followed), mode 0600."""
+    import os
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    with os.fdopen(fd, "wb") as f:
+        f.write(data)
 
 
 def exchange_unique_id(rank: int, world: int, path: Optional[str] = None, make_id=comm_unique_id, timeout_s: float = 120.0) -> bytes:
-    """Rank 0 writes the id (atomic rename), the others wait for the file.  Single node only (shared /tmp)."""
+    """Rank 0 writes the id (exclusive create + atomic rename), the others wait for the file.  Single node only (shared /tmp)."""
     import os
     import time
     path = path or rendezvous_path()
@@ -137,18 +154,26 @@ def exchange_unique_id(rank: int, world: int, path: Optional[str] = None, make_i
         try:
             uid = make_id()
         except Exception:
-            with open(path, "wb") as f:  # tell the waiting ranks at once instead of letting them run into the timeout
-                f.write(b"failed")
+            try:
+                _write_new(path, b"failed")  # tell the waiting ranks at once instead of letting them run into the timeout
+            except OSError:
+                pass
             raise
         tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
-            f.write(uid)
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        _write_new(tmp, uid)
         os.replace(tmp, path)
         return uid
     t0 = time.time()
     while True:
         try:
-            with open(path, "rb") as f:
+            fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+            with os.fdopen(fd, "rb") as f:
+                if os.fstat(f.fileno()).st_uid != os.getuid():
+                    raise RuntimeError("rendezvous file %s belongs to another user" % path)
                 uid = f.read()
             if len(uid) == 128:
                 return uid

@@ -126,7 +126,7 @@ def cpu_baseline(inst, c):
     osc = O.Scene(inst.bvh.nodes, inst.bvh.tri_indices, inst.scene.triangles, inst.scene.materials, textures=inst.scene.textures)
     ip, iv = O.camera(c.fov, c.yaw, c.pitch, c.width, c.height)
     P = O.make_params(c.width, c.height, list(c.position), ip, iv, stack_size=c.stack_size, max_bounce=c.max_bounce, subpixel=c.subpixel,
-                      tmp_life=1, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))
+                      tmp_life=c.tmp_lifetime, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))  # the bench's own tmpLifetime: same rays per frame
     sm = np.fromfile(os.path.join(ROOT, "tests", "golden", "sobol_matrices_64x32.u32"), dtype=np.uint32).reshape(64, 32)
     cores = O.default_threads()
     stc = O.PathTracerState(c.width, c.height)
@@ -140,14 +140,14 @@ def cpu_baseline(inst, c):
         frames += 1
     # one thread (SURVEY.md §8d asks for both): a quarter-height frame keeps it to a few seconds
     P1 = O.make_params(c.width, c.height // 4, list(c.position), *O.camera(c.fov, c.yaw, c.pitch, c.width, c.height // 4), stack_size=c.stack_size,
-                       max_bounce=c.max_bounce, subpixel=c.subpixel, tmp_life=1, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))
+                       max_bounce=c.max_bounce, subpixel=c.subpixel, tmp_life=1, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))  # one frame: it traces its primaries
     st1 = O.PathTracerState(c.width, c.height // 4)
     t1 = time.perf_counter()
     s1 = O.pt_frames(osc, P1, O.shift_bytes(SEED, c.width, c.height // 4), sm, st1, 1, n_threads=1)
     t1 = time.perf_counter() - t1
     return {"value": round(cpu_rays / cpu_t / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d full %dx%d frames (every frame traces its primaries), %d rays, %.1f s, oracle/liboracle.so on %d threads"
-                      % (frames, c.width, c.height, cpu_rays, cpu_t, cores),
+            "sample": "%d full %dx%d frames starting at frame 0 with the bench's tmpLifetime %d (cached primaries are not rays), %d rays, %.1f s, oracle/liboracle.so on %d threads"
+                      % (frames, c.width, c.height, c.tmp_lifetime, cpu_rays, cpu_t, cores),
             "value_1_thread": round(s1.rays / t1 / 1e6, 3),
             "sample_1_thread": "one %dx%d frame, %d rays, %.1f s" % (c.width, c.height // 4, s1.rays, t1)}
 
@@ -213,20 +213,27 @@ def main() -> None:
     t_setup = time.time() - t_setup
 
     if world > 1 and not use_torch:
+        # Two failure classes.  (a) rank 0 cannot even make an RCCL id (library not found, symbol missing): it leaves a marker in the
+        # rendezvous file, EVERY rank sees the same RuntimeError, and all of them take the torch.distributed variant of the same gather
+        # together.  (b) anything later (ncclCommInitRank on one rank, a timeout) may have happened on this rank alone while the others
+        # sit inside RCCL: falling back here would hang the job, so the rank exits non-zero and the launcher tears the job down.
         try:
-            pt.CommInit(D.exchange_unique_id(rank, world))  # the ranks' only exchange outside RCCL: the 128-byte communicator id
-            pt.CommBarrier()
-        except (N.AdyptError, OSError, TimeoutError, RuntimeError) as e:
-            # the library could not bring RCCL up by itself (library not found, symbol missing: the same on every rank): the
-            # torch.distributed variant of the same gather still gives the scaling run a number, and the line says which one ran
-            sys.stderr.write("bench.py rank %d: native RCCL communicator failed (%s); falling back to --comm torch\n" % (rank, e))
+            uid = D.exchange_unique_id(rank, world)
+        except RuntimeError as e:
+            sys.stderr.write("bench.py rank %d: no native RCCL id (%s); all ranks fall back to --comm torch\n" % (rank, e))
             use_torch = True
             init_torch()
-        if rank == 0:  # every rank holds the communicator now: a later job must never find this id
+        else:
             try:
-                os.remove(D.rendezvous_path())
-            except OSError:
-                pass
+                pt.CommInit(uid)  # the ranks' only exchange outside RCCL was the 128-byte communicator id
+                pt.CommBarrier()
+            except (N.AdyptError, OSError) as e:
+                raise SystemExit("bench.py rank %d: native RCCL communicator failed (%s)" % (rank, e))
+            if rank == 0:  # every rank holds the communicator now: a later job must never find this id
+                try:
+                    os.remove(D.rendezvous_path())
+                except OSError:
+                    pass
 
     if use_torch:
         n_pad = D.max_block_count(c.width, c.height, world) * D.BLOCK_PIXELS * 4

@@ -9,7 +9,7 @@
  * glNamedBufferStorage(..., flags = 0) uploads of src/Tracer/OglScene.cpp:125-134).
  *
  * Threading: one host thread drives a context; calls are synchronous unless stated; a context is bound to one
- * HIP device and owns one HIP stream.  No exceptions cross this boundary: every call returns ADYPT_OK (0) or a
+ * HIP device and owns its HIP streams.  No exceptions cross this boundary: every call returns ADYPT_OK (0) or a
  * negative ADYPT_E_* code and adypt_last_error() gives the text (the reference printf()s and returns bool).
  */
 #ifndef ADYPT_HIP_H
@@ -137,6 +137,15 @@ int adypt_get_spp(const adypt_ctx *ctx); /* OglPathTracer::GetSPP */
  * the trace calls return ADYPT_E_STATE. */
 int adypt_set_frames_in_flight(adypt_ctx *ctx, int n_frames);
 int adypt_get_frames_in_flight(const adypt_ctx *ctx);
+/* How many sub-batches a batch of frames is cut into (1..4, default 2; ADYPT_PIPELINE in the environment overrides the
+ * default).  Each sub-batch is the chain camera rays -> [traversal -> shade] x maxBounce on its own HIP stream over its own
+ * window of the ray queues, so one chain's traversal launch covers the drain of the other's and the time the other's shade
+ * kernel spends streaming the queues through HBM — the wavefront counterpart of the reference's single dispatch that runs the
+ * whole bounce loop without a barrier (shaders/pathtracer.glsl:107, src/Tracer/OglPathTracer.cpp:60).  1 = one chain on the
+ * context's stream (kernel timings of adypt_get_stats are then of launches that had the GPU to themselves).  Results are
+ * bit-identical for every value. */
+int adypt_set_pipeline(adypt_ctx *ctx, int n_pipes);
+int adypt_get_pipeline(const adypt_ctx *ctx);
 /* Look-ahead for callers that ask for ONE frame per call, as Instance::Update does (src/Instance.cpp:44-57 -> Trace(true),
  * src/Tracer/OglPathTracer.cpp:34-61).  Off (default): adypt_trace_spp(ctx, n) traces exactly n frames.  On: a call that
  * needs frames not traced yet traces a whole pass of frames_in_flight frames — frame k's sample depends only on k (Sobol

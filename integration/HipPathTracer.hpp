@@ -109,8 +109,14 @@ public:
 	// OglScene::Initialize(scene, bvh) + OglPathTracer::Initialize(config, oglscene, width, height).
 	// devices: HIP device ordinals; with more than one the frame is sharded by 32x32 pixel tile over them (scene replicated,
 	// no communication while rendering) and SaveResult gathers the radiance on devices[0] over RCCL.
+	// lookahead_frames: Instance::Update calls Trace(true) once per window frame.  0 (default, the windowed application): every call
+	// traces exactly its one frame — even frame pacing, the smallest ray queues (1 frame in flight: ~0.4 GB per device at 1080p).
+	// N > 0 (headless rendering, e.g. the CLI loop that calls Trace(true) spp times and then SaveResult): a call that needs an untraced
+	// frame traces a whole wavefront pass of N frames and the following N - 1 calls only apply their running-mean step — 1.4x the
+	// rays per second (DESIGN.md §4 "one frame per call"), but bursty: one call in N takes N frames' time, and the queues grow to
+	// N frames in flight (8 x 16 B x N x pixels per device).  Images are bit-identical either way.
 	bool Initialize(const InstanceConfig::PT *config, const Scene &scene, const WideBVH &bvh, int width, int height,
-	                const std::vector<int> &devices = std::vector<int>(1, 0))
+	                const std::vector<int> &devices = std::vector<int>(1, 0), int lookahead_frames = 0)
 	{
 		m_config = config; m_width = width; m_height = height;
 		init_materials(scene);
@@ -124,9 +130,10 @@ public:
 		d.textures = m_textures.data();             d.n_textures = (int32_t)m_textures.size();
 		d.width = width; d.height = height;
 		if(adypt_create_multi(&m_gpus, &d, devices.data(), (int)devices.size()) != ADYPT_OK) { printf("[PT]ERR: %s\n", adypt_multi_last_error(nullptr)); return false; }
-		// Instance::Update calls Trace(true) once per window frame: let the library trace a whole wavefront pass on the first
-		// call and hand the finished frames out one per call (bit-identical images, adypt_hip.h adypt_set_lookahead)
-		adypt_multi_set_lookahead(m_gpus, 1);
+		const int fif = lookahead_frames > 0 ? (lookahead_frames < 128 ? lookahead_frames : 128) : 1;
+		for(int i = 0; i < adypt_multi_device_count(m_gpus); ++i)
+			if(adypt_set_frames_in_flight(adypt_multi_context(m_gpus, i), fif) != ADYPT_OK) { printf("[PT]ERR: %s\n", adypt_last_error(adypt_multi_context(m_gpus, i))); return false; }
+		adypt_multi_set_lookahead(m_gpus, lookahead_frames > 0 ? 1 : 0);
 		return update_config_args();
 	}
 

@@ -33,7 +33,8 @@ int main(int argc, char **argv)
 		WideBVHBuilder{config.m_bvh_cfg, &wbvh, sbvh}.Run();
 	}
 	HipPathTracer tracer;
-	if(!tracer.Initialize(&config.m_pt_cfg, scene, wbvh, config.m_width, config.m_height)) return 1;
+	// headless: look-ahead on (a pass of up to 32 frames per traced call), as a render-to-EXR loop would use it
+	if(!tracer.Initialize(&config.m_pt_cfg, scene, wbvh, config.m_width, config.m_height, std::vector<int>(1, 0), 32)) return 1;
 	// Camera::GetView / GetProjection (src/Tracer/Camera.cpp:13-23; Camera.cpp itself needs GLFW and ImGui for Control())
 	const InstanceConfig::Cam &cam = config.m_cam_cfg;
 	glm::mat4 view = glm::rotate(glm::identity<glm::mat4>(), glm::radians(-cam.m_pitch), glm::vec3(1.0f, 0.0f, 0.0f));

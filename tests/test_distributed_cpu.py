@@ -127,3 +127,32 @@ def test_native_rendezvous_tells_waiting_ranks_when_rank0_cannot_make_an_id(tmp_
     with pytest.raises(RuntimeError):
         D.exchange_unique_id(1, 2, path=path, timeout_s=30.0)
     assert time.time() - t0 < 5.0
+
+
+def test_rendezvous_file_lives_in_a_private_directory_and_is_never_followed_through_a_symlink(tmp_path, monkeypatch):
+    """the id file used to sit in shared /tmp under a predictable name, opened with plain open()."""
+    import stat
+    from adypt_amd import distributed as D
+    monkeypatch.delenv("ADYPT_RENDEZVOUS_DIR", raising=False)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    import tempfile
+    tempfile.tempdir = None  # re-read TMPDIR
+    try:
+        monkeypatch.setenv("MASTER_PORT", "29999")
+        monkeypatch.setenv("ADYPT_RUN_ID", "job/../7")  # hostile characters are flattened, the parent pid is not part of the name
+        p = D.rendezvous_path()
+        d = os.path.dirname(p)
+        assert os.path.dirname(d) == str(tmp_path) and stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+        assert "/" not in os.path.basename(p) and ".." not in os.path.basename(p).replace("_.._", "") and str(os.getppid()) not in os.path.basename(p)
+        # a symlink planted at the file's path is neither written through (rank 0) nor read through (other ranks)
+        target = tmp_path / "victim"
+        target.write_bytes(b"x" * 128)
+        os.symlink(str(target), p)
+        with pytest.raises(TimeoutError):
+            D.exchange_unique_id(1, 2, path=p, timeout_s=0.3)
+        os.unlink(p)
+        os.symlink(str(target), p + ".tmp%d" % os.getpid())
+        assert D.exchange_unique_id(0, 2, path=p, make_id=lambda: bytes(range(128))) == bytes(range(128))
+        assert target.read_bytes() == b"x" * 128 and not os.path.islink(p)
+    finally:
+        tempfile.tempdir = None

@@ -141,3 +141,44 @@ def test_long_progressive_run_is_bit_exact(scene_cache, sobol_matrices):
         O.pt_frames(osc, P, shift, sobol_matrices, state, n)
         assert np.array_equal(bits(p.ReadResult()), bits(state.accum[..., :3])), "after %d samples" % p.GetSPP()
     assert p.GetSPP() == 1100
+
+
+@pytest.mark.parametrize("name,w,h,life,fif,spp,sunvis", [("tiny0", 100, 75, 4, 13, 29, False), ("tiny0", 96, 64, 16, 32, 40, False),
+                                                            ("sibenik", 160, 90, 3, 7, 17, False), ("tiny0", 72, 40, 1, 5, 12, True),
+                                                            ("tiny0", 64, 48, 5, 3, 8, True)])
+def test_pipeline_of_sub_batches_is_bit_invariant(name, w, h, life, fif, spp, sunvis, scene_cache, sobol_matrices, monkeypatch):
+    """adypt_set_pipeline: a batch cut into 1..4 sub-batches, each the chain camera rays -> [traversal -> shade] x maxBounce on
+    its own HIP stream in its own window of the ray queues (the chains overlap on the GPU).  Image, spp, image 1 and the exact
+    work counters equal the oracle's / the serial chain's for every split, including sub-batches of unequal size, a batch
+    smaller than the number of pipes, the sun-visibility queues and traversal stacks that spill out of LDS."""
+    monkeypatch.setenv("ADYPT_LDS_STACK_DEPTH", "2")  # deeper entries go to the per-pipe spill arrays: two pipes' launches overlap
+    pt_cfg = {"tmpLifetime": life, "maxBounce": 6, "subpixel": 3}
+    ref = None
+    for pipes in (1, 2, 3, 4):
+        inst = _instance(scene_cache, name, w, h, pt_cfg)
+        p, c = inst.m_path_tracer, inst.m_config.c
+        p.SetFramesInFlight(fif)
+        p.SetPipeline(pipes)
+        assert p.GetPipeline() == pipes
+        if sunvis:
+            p.SetSunVisibility(True)
+        p.SetInstrumentation(counters=True)
+        p.ResetStats()
+        p.Trace(True, spp - 2)
+        p.Trace(True, 2)
+        img, st = p.ReadResult(), p.GetStats()
+        tri, uv = p.ReadHits()
+        assert p.GetSPP() == spp and st["stack_overflows"] == 0
+        if ref is None:
+            ref = (img, st, tri, uv)
+            if not sunvis:
+                osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+                state = O.PathTracerState(c.width, c.height)
+                ost = O.pt_frames(osc, P, O.shift_bytes(31, c.width, c.height), sobol_matrices, state, spp).as_dict()
+                assert np.array_equal(bits(img), bits(state.accum[..., :3]))
+                assert (st["rays"], st["nodes_visited"], st["tris_tested"], st["shaded"]) == (ost["rays"], ost["nodes"], ost["tris"], ost["shaded"])
+        else:
+            assert np.array_equal(bits(img), bits(ref[0])), "%d pipes changed the image" % pipes
+            for k in ("rays", "nodes_visited", "tris_tested", "hits", "shaded", "max_stack"):
+                assert st[k] == ref[1][k], (pipes, k)
+            assert np.array_equal(tri, ref[2]) and np.array_equal(bits(uv), bits(ref[3]))

@@ -313,6 +313,48 @@ def test_corrupt_jpegs_fail_cleanly(tmp_path):
             pass
 
 
+def test_jpeg_with_sampling_factors_that_do_not_divide_the_maximum_is_rejected(tmp_path):
+    """Components sampled 2x1, 3x1, 1x1 have no integer chroma up-sampling step: the row filters would read W samples from rows that
+    hold fewer (heap over-read in the copy of stb_image the reference vendors, dep/stb_image.h:2976-2977 accepts any 1..4).  The
+    frame header must be refused; splicing the bad header into a real file (valid tables and scan data behind it) must be too."""
+    def sof(h_v):
+        comps = b"".join(bytes([i + 1, hv, 0]) for i, hv in enumerate(h_v))
+        return b"\xff\xc0" + (8 + 3 * len(h_v)).to_bytes(2, "big") + b"\x08" + (16).to_bytes(2, "big") + (2400).to_bytes(2, "big") + bytes([len(h_v)]) + comps
+    for h_v in ((0x21, 0x31, 0x11), (0x31, 0x21, 0x11), (0x13, 0x12, 0x11), (0x41, 0x31, 0x31)):
+        (tmp_path / "bad.jpg").write_bytes(b"\xff\xd8" + sof(h_v) + b"\xff\xda" + b"\x00" * 64 + b"\xff\xd9")
+        with pytest.raises(N.AdyptError) as e:
+            api.load_image_rgb8(str(tmp_path / "bad.jpg"))
+        assert e.value.code == N.E_PARSE and "do not divide" in str(e.value), h_v
+    good = open(os.path.join(GOLDEN, "images", "j420_progressive_restart.jpg"), "rb").read()
+    at = good.index(b"\xff\xc2")  # progressive SOF of the fixture
+    n = int.from_bytes(good[at + 2:at + 4], "big")
+    hdr = bytearray(good[at:at + 2 + n])
+    assert hdr[9] == 3
+    hdr[11], hdr[14], hdr[17] = 0x21, 0x31, 0x11
+    (tmp_path / "spliced.jpg").write_bytes(good[:at] + bytes(hdr) + good[at + 2 + n:])
+    with pytest.raises(N.AdyptError):
+        api.load_image_rgb8(str(tmp_path / "spliced.jpg"))
+    # factors that do divide stay accepted (4:1:1 fixture: 4x1, 1x1, 1x1)
+    assert api.load_image_rgb8(os.path.join(GOLDEN, "images", "j420_progressive_restart.jpg")).ndim == 3
+
+
+def test_huge_tga_and_bmp_headers_are_errors_not_allocations(tmp_path):
+    """An 18-byte TGA header / a BMP header claiming 65535 x 65535 (or sizes whose stride * height wraps) must fail before anything of
+    that size is allocated: no exception may cross the C ABI (adypt_load_image_rgb8 returns ADYPT_E_PARSE / ADYPT_E_OOM)."""
+    tga = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0]) + (65535).to_bytes(2, "little") * 2 + bytes([24, 0])
+    (tmp_path / "huge.tga").write_bytes(tga)
+    with pytest.raises(N.AdyptError):
+        api.load_image_rgb8(str(tmp_path / "huge.tga"))
+    for w, h in ((0x7fffffff, 0x7fffffff), (65535, 65535), (1 << 20, 1 << 20)):
+        bmp = bytearray(b"BM" + b"\x00" * 52)
+        bmp[10:14] = (54).to_bytes(4, "little"); bmp[14:18] = (40).to_bytes(4, "little")
+        bmp[18:22] = w.to_bytes(4, "little"); bmp[22:26] = h.to_bytes(4, "little")
+        bmp[26:28] = (1).to_bytes(2, "little"); bmp[28:30] = (24).to_bytes(2, "little")
+        (tmp_path / "huge.bmp").write_bytes(bytes(bmp))
+        with pytest.raises(N.AdyptError):
+            api.load_image_rgb8(str(tmp_path / "huge.bmp"))
+
+
 def test_obj_face_index_out_of_range_is_an_error(tmp_path):
     """tinyobj stores whatever index a face gives and the reference's Scene.cpp reads attrib.vertices[3 * idx] unchecked
     (src/Util/Scene.cpp:60-75): undefined behaviour there, a load error here (found by tools/fuzz_loaders.cpp)."""
