@@ -10,6 +10,7 @@
 // (one dispatch runs the whole for(b < uMaxBounce) loop, shaders/pathtracer.glsl:107); results do not depend on any of this:
 // per-path work is independent of queue order and k_resolve applies the finished samples in frame order.
 // There is no CPU fallback anywhere in this file: without a HIP device adypt_create fails with ADYPT_E_NO_DEVICE.
+#define ADYPT_TRACER_TU // (measure/k_trace_ablations.hpp defines its read-back entry point in this translation unit only)
 #include "traverse.hpp"
 #include "ctx_access.hpp"
 #include "../../../include/adypt_hip.h"
@@ -29,7 +30,7 @@ namespace {
 constexpr int kMaxBounce = 32;
 constexpr int kMaxFramesInFlight = 128;
 constexpr int kMaxPipes = 4;           // sub-batches of a batch that run as concurrent chains (adypt_set_pipeline)
-constexpr int kDefaultPipes = 2;
+constexpr int kDefaultPipes = 1;       // measured: a second chain overlaps but recovers nothing (profiles/r3_ablations_k_trace.txt)
 
 struct FrameCounters {                 // one memset per frame; every counter on its own 128-byte line
 	uint32_t count[kMaxBounce + 1][kNumSegments * kCursorStride];   // live rays per queue segment after bounce b

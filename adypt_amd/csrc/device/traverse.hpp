@@ -31,6 +31,12 @@
 #define ADYPT_MEASURE_AFTER_NODE_LOADS(np, lane)
 #define ADYPT_MEASURE_AFTER_SLAB_TEST(aox, aoy, aoz, aix, aiy)
 #endif
+#ifndef ADYPT_MEASURE_WAVE_TIMELINE
+#define ADYPT_MEASURE_WAVE_BEGIN()
+#define ADYPT_MEASURE_WAVE_FIRST_RAYS()
+#define ADYPT_MEASURE_WAVE_QUEUE_DRY()
+#define ADYPT_MEASURE_WAVE_END(stats)
+#endif
 
 namespace adypt {
 
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
 	const int home = blockIdx.x & (kNumSegments - 1);
 
+	ADYPT_MEASURE_WAVE_BEGIN();
 	if(blockIdx.x == 0 && threadIdx.x == 0)
 	{
 		unsigned long long total = 0;
@@ -130,7 +137,8 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				uint32_t cb = 0;
 				const uint32_t cn = fetch_rays(seg_len_lanes, seg_done, a.cursor, a.seg_cap, home, a.chunk, &cb);
 				loc_next = cb; loc_end = cb + cn;
-				if(cn == 0) exhausted = true;
+				if(cn == 0) { exhausted = true; ADYPT_MEASURE_WAVE_QUEUE_DRY(); }
+				else { ADYPT_MEASURE_WAVE_FIRST_RAYS(); }
 			}
 			const uint32_t begin = loc_next;
 			const uint32_t got = min(n_idle, loc_end - loc_next);
@@ -402,6 +410,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 		const int32_t tri_id = hit_idx != -1 ? a.tri_indices[hit_idx] : -1;
 		a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
 	}
+	ADYPT_MEASURE_WAVE_END(a.stats);
 	if(any_overflow) atomicAdd(&a.stats->overflows, 1ull);
 	if(STATS)
 	{

@@ -47,3 +47,23 @@
 #else
 #define ADYPT_MEASURE_AFTER_SLAB_TEST(aox, aoy, aoz, aix, aiy)
 #endif
+
+// Wave timeline of ONE traversal launch (tools/wave_timeline.py): when do the persistent waves start, get their first rays, find the queue
+// dry, end?  100 MHz wall clock, one record of 4 timestamps per wave in a device array (atomics on shared words would cost more than
+// the launch: ~88 same-address atomics per microsecond), read back through adypt_debug_read_timeline (this build only).
+#ifdef ADYPT_ABLATE_WAVE_TIMELINE
+#define ADYPT_MEASURE_WAVE_TIMELINE
+namespace adypt { __device__ unsigned long long g_wave_timeline[8192 * 4]; }
+#define ADYPT_MEASURE_WAVE_BEGIN() const unsigned long long tl_begin = wall_clock64(); unsigned long long tl_first = 0, tl_dry = 0
+#define ADYPT_MEASURE_WAVE_FIRST_RAYS() if(tl_first == 0) tl_first = wall_clock64()
+#define ADYPT_MEASURE_WAVE_QUEUE_DRY() if(tl_dry == 0) tl_dry = wall_clock64()
+#define ADYPT_MEASURE_WAVE_END(stats)                                                                                           \
+	if(!STATS && lane == 0)                                                                                                     \
+	{                                                                                                                           \
+		const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;                                                        \
+		if(w < 8192) { unsigned long long *o = adypt::g_wave_timeline + (size_t)w * 4; o[0] = tl_begin; o[1] = tl_first; o[2] = tl_dry; o[3] = wall_clock64(); } \
+	}
+#ifdef ADYPT_TRACER_TU
+extern "C" int adypt_debug_read_timeline(unsigned long long *out) { (void)hipDeviceSynchronize(); return hipMemcpyFromSymbol(out, HIP_SYMBOL(adypt::g_wave_timeline), sizeof(unsigned long long) * 8192 * 4) == hipSuccess ? 0 : -3; }
+#endif
+#endif

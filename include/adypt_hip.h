@@ -137,7 +137,7 @@ int adypt_get_spp(const adypt_ctx *ctx); /* OglPathTracer::GetSPP */
  * the trace calls return ADYPT_E_STATE. */
 int adypt_set_frames_in_flight(adypt_ctx *ctx, int n_frames);
 int adypt_get_frames_in_flight(const adypt_ctx *ctx);
-/* How many sub-batches a batch of frames is cut into (1..4, default 2; ADYPT_PIPELINE in the environment overrides the
+/* How many sub-batches a batch of frames is cut into (1..4, default 1; ADYPT_PIPELINE in the environment overrides the
  * default).  Each sub-batch is the chain camera rays -> [traversal -> shade] x maxBounce on its own HIP stream over its own
  * window of the ray queues, so one chain's traversal launch covers the drain of the other's and the time the other's shade
  * kernel spends streaming the queues through HBM — the wavefront counterpart of the reference's single dispatch that runs the
