@@ -41,8 +41,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec)
-VALU_PEAK_GCYCLES = 1024 * 2.4  # 256 CUs x 4 SIMDs x 2.4 GHz: vector-ALU issue cycles per second (a full-rate wave64 instruction takes
-                                # 2 of them, most of this kernel's take 4: profiles/r2_valu_throughput_microbench.txt)
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+NOMINAL_CLOCK_GHZ = 2.4 # only used when no profile supplies the clock the chip really ran the kernel at
+PMC_BENCH, PMC_SANMIGUEL, ISSUE_MODEL = "r3_pmc_bench.json", "r3_pmc_sanmiguel.json", "r3_valu_issue_model.json"
 PT_CFG = {"maxBounce": 8, "subpixel": 8, "clamp": 4.0, "sun": [12.0, 11.0, 10.0], "stackSize": 24}
 SEED = 12345
 
@@ -52,6 +53,58 @@ def load_profile(name):
         return json.load(open(os.path.join(ROOT, "profiles", name)))
     except (OSError, ValueError):
         return None
+
+
+def counter_figures(name):
+    """Per-ray counter figures of the traversal kernel from the committed rocprofv3 --pmc passes (tools/collect_profiles.sh ->
+    tools/pmc_profile.py), or None with the reason when the file is missing or was measured on other device sources."""
+    from tools.source_hash import device_source_hash
+    pmc = load_profile(name)
+    if not pmc:
+        return None, "profiles/%s missing" % name
+    now = device_source_hash()
+    if pmc.get("source_hash") != now:
+        return None, "profiles/%s was measured on device sources %s, this tree is %s: re-run tools/collect_profiles.sh" % (name, pmc.get("source_hash"), now)
+    return pmc, None
+
+
+def valu_roofline(pmc, model, kernel_rays_s):
+    """The vector-ALU issue roof of the traversal kernel.  Everything is a formula over the committed profile and ONE live number:
+      peak      = 1024 SIMDs x effective clock, effective clock = GRBM_GUI_ACTIVE / 8 XCDs / launch duration (kernel trace of the same command)
+      achieved  = SIMD cycles with a vector-ALU instruction executing, per second = SQ_ACTIVE_INST_VALU x 4 per ray (profile) x rays/s (live)
+      frac      = achieved / peak  (>= 1 when the 4-cycle quanta of the counter over-count: read it as 'saturated')
+    and, next to it, the microbenchmark model: instructions per ray (SQ_INSTS_VALU) x rays/s x the average time an instruction of this
+    kernel's mix holds the SIMD, with the rounded (2 / 4 / 4 / 8 'cycles') and with the measured class rates — times at the
+    microbenchmark's nominal 2.4 GHz, NOT cycles at the effective clock."""
+    clock = pmc.get("effective_clock_GHz")
+    peak = N_SIMD * (clock or NOMINAL_CLOCK_GHZ)
+    busy_cycles_per_ray = pmc["SQ_ACTIVE_INST_VALU_per_launch"] * 4.0 * pmc["launches"] / pmc["rays"]
+    achieved = busy_cycles_per_ray * kernel_rays_s / 1e9
+    out = {"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "Gcycle/s", "frac": round(achieved / peak, 4),
+           "effective_clock_GHz": round(clock, 3) if clock else None, "lane_util": round(pmc["lane_util"], 4),
+           "useful_frac": round(min(1.0, achieved / peak) * pmc["lane_util"], 4),
+           "valu_busy_frac_in_profile": round(pmc["valu_busy_frac"], 4), "valu_insts_per_ray": round(pmc["valu_insts_per_ray"], 2),
+           "valu_Ginst_s": round(pmc["valu_insts_per_ray"] * kernel_rays_s / 1e9, 1), "pmc_stale": False, "pmc_source_hash": pmc["source_hash"]}
+    if model:
+        inst_rate = pmc["valu_insts_per_ray"] * kernel_rays_s
+        for tag in ("rounded", "measured"):
+            c = model["avg_issue_cycles_per_inst_" + tag]
+            out["model_avg_issue_cycles_per_inst_" + tag] = c
+            out["model_frac_" + tag + "_rates"] = round(inst_rate * c / (N_SIMD * model["nominal_clock_GHz_of_the_microbench_figures"] * 1e9), 4)
+        if "vmem_rd_insts_per_ray" in pmc:  # the co-limiter: the CU's one vector-memory pipeline (profiles/r2_ablations_k_trace.txt)
+            out["vmem_busy_est"] = round(pmc["vmem_rd_insts_per_ray"] * kernel_rays_s * model["vmem_cycles_per_load_inst"] / (256 * model["nominal_clock_GHz_of_the_microbench_figures"] * 1e9), 3)
+    return out
+
+
+def traffic_fields(pmc, rays, launches, kernel_rays_s):
+    """Fabric-side bytes from the PMC counters: FETCH_SIZE (KB; x 2 on gfx950 for 16-byte-per-lane loads, MI355X_MICROARCH.md) + WRITE_SIZE,
+    per ray (profile) x the rays per launch of this run; also without the x 2 (the correction is calibrated on coalesced streaming)."""
+    return {"traffic": round(pmc["traffic_bytes_per_ray"] * rays / max(1, launches)),
+            "traffic_GBs": round(pmc["traffic_bytes_per_ray"] * kernel_rays_s / 1e9, 1),
+            "traffic_frac_of_hbm_peak": round(pmc["traffic_bytes_per_ray"] * kernel_rays_s / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic_uncorrected": round(pmc.get("traffic_bytes_per_ray_uncorrected", 0.0) * rays / max(1, launches)),
+            "traffic_uncorrected_frac_of_hbm_peak": round(pmc.get("traffic_bytes_per_ray_uncorrected", 0.0) * kernel_rays_s / 1e9 / HBM_PEAK_GBS, 4),
+            "l2_hit_rate": round(pmc.get("TCC_hit_rate", 0.0), 3)}
 
 
 def census(pt, steps, warmup, expect_rays=None):
@@ -91,31 +144,34 @@ def hbm_resident_block(args, dev):
     cs = census(pt, steps, warmup, st["rays"])
     bvh_mb = (len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 52) / 1e6
     achieved = cs["alg_bytes"] / (st["trace_ms"] * 1e-3) / 1e9
-    out = {"bound": "hbm", "kernel": "k_trace<false, false>",
+    rays_s = st["rays"] / (st["trace_ms"] * 1e-3)
+    out = {"kernel": "k_trace<false, false>",
            "workload": "sanmiguel-like procedural stand-in (%s), %d triangles, BVH %.0f MB (nodes + Woop + index) > 256 MB Infinity Cache, 1920x1080, 8 bounces, %d frames after %d warm-up"
                        % (spec.label, inst.scene.n_tris, bvh_mb, steps, warmup),
-           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+           "alg_GBs": round(achieved, 1), "alg_frac_of_hbm_peak": round(achieved / HBM_PEAK_GBS, 4), "hbm_peak_GBs": HBM_PEAK_GBS,
            "launches": int(st["trace_launches"]), "avg_launch_ms": round(st["trace_ms"] / max(1, st["trace_launches"]), 4),
            "alg_bytes_per_launch": round(cs["alg_bytes"] / max(1, st["trace_launches"])), "alg_bytes_per_ray": round(cs["alg_bytes"] / cs["rays"], 1),
            "nodes_per_ray": round(cs["nodes_visited"] / cs["rays"], 2), "tris_per_ray": round(cs["tris_tested"] / cs["rays"], 2),
-           "trace_kernel_Mrays_s": round(st["rays"] / (st["trace_ms"] * 1e3), 1), "whole_frame_Mrays_s": round(st["rays"] / wall / 1e6, 1),
+           "trace_kernel_Mrays_s": round(rays_s / 1e6, 1), "whole_frame_Mrays_s": round(st["rays"] / wall / 1e6, 1),
            "trace_kernels_ms": round(st["trace_ms"], 2), "shade_kernels_ms": round(st["shade_ms"], 2), "setup_s": round(setup_s, 1)}
-    pmc = load_profile("r2_pmc_sanmiguel.json")
-    if pmc and "traffic_bytes_per_ray" in pmc:
-        out["traffic"] = round(pmc["traffic_bytes_per_ray"] * st["rays"] / max(1, st["trace_launches"]))
-        out["traffic_GBs"] = round(pmc["traffic_bytes_per_ray"] * st["rays"] / (st["trace_ms"] * 1e-3) / 1e9, 1)
-        out["traffic_over_algorithmic"] = round(pmc["traffic_bytes_per_ray"] / (cs["alg_bytes"] / cs["rays"]), 3)
-        out["traffic_source"] = "profiles/r2_pmc_sanmiguel.json: %.1f fabric bytes per ray (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024, separate rocprofv3 --pmc passes of %s) x the rays per launch of this run" % (
-            pmc["traffic_bytes_per_ray"], pmc.get("command", "bench.py --scene sanmiguel"))
-        mix = load_profile("r2_k_trace_instruction_mix.json")
-        if mix and "valu_insts_per_ray" in pmc:
-            rays_s = st["rays"] / (st["trace_ms"] * 1e-3)
-            out["valu_issue_frac"] = round(pmc["valu_insts_per_ray"] * rays_s * mix["avg_issue_cycles_per_inst"] / 1e9 / VALU_PEAK_GCYCLES, 4)
-            out["lane_util"] = round(pmc["lane_util"], 4)
-            out["note"] = ("algorithmic bytes (SURVEY.md §8d) / HIP-event time against the HBM peak, as the contract defines it.  The counters show what is "
-                           "behind it: the L2s still catch %.0f %% of the requests (the top of the tree), so the fabric carries %.2f of the algorithmic bytes, and "
-                           "the vector ALUs are busy for valu_issue_frac of the time — on this scene the kernel sits between the two roofs"
-                           % (100 * pmc.get("TCC_hit_rate", 0.0), pmc["traffic_bytes_per_ray"] / (cs["alg_bytes"] / cs["rays"])))
+    pmc, why = counter_figures(PMC_SANMIGUEL)
+    if pmc:
+        out.update(traffic_fields(pmc, st["rays"], st["trace_launches"], rays_s))
+        valu = valu_roofline(pmc, load_profile(ISSUE_MODEL), rays_s)
+        # what binds here is neither roof alone: the fraction reported is the counter-measured fabric traffic against the HBM peak — a valid
+        # fraction (an upper bound on HBM bytes: Infinity-Cache hits are in it); the algorithmic figure exceeds what reaches the fabric because
+        # the L2s catch the top of the tree, and the vector ALUs are busy for valu_issue_frac of the cycles
+        out.update({"bound": "between hbm and valu_issue", "achieved": out["traffic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": out["traffic_frac_of_hbm_peak"], "valu_issue_frac": valu["frac"], "lane_util": valu["lane_util"],
+                    "effective_clock_GHz": valu["effective_clock_GHz"], "pmc_stale": False,
+                    "traffic_over_algorithmic": round(pmc["traffic_bytes_per_ray"] / (cs["alg_bytes"] / cs["rays"]), 3),
+                    "note": "achieved / frac = fabric-side bytes of the traversal launches (PMC FETCH_SIZE x 2 + WRITE_SIZE of %s, per ray) x this run's rays/s "
+                            "against 8 TB/s; traffic_uncorrected = the same without the x 2.  alg_frac_of_hbm_peak (SURVEY.md 8d bytes / HIP-event time / 8 TB/s) "
+                            "is NOT a fraction of HBM traffic: the L2s catch %.0f %% of the requests.  valu_issue_frac: bench.py valu_roofline()"
+                            % (pmc.get("command", "?"), 100 * pmc.get("TCC_hit_rate", 0.0))})
+    else:
+        out.update({"bound": "hbm (algorithmic bytes only)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                    "traffic": None, "pmc_stale": True, "note": "no counter figures: " + why + "; alg_frac_of_hbm_peak is cache assisted and not reported as a fraction"})
     pt.destroy()
     return out
 
@@ -307,38 +363,26 @@ def main() -> None:
                 "nodes_per_ray": round(cs["nodes_visited"] / max(1, cs["rays"]), 2), "tris_per_ray": round(cs["tris_tested"] / max(1, cs["rays"]), 2),
                 "alg_GBs": round(alg_gbs, 1), "alg_frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "hbm_peak_GBs": HBM_PEAK_GBS,
                 "traffic": None}
-    # The PMC counters cannot be read from inside this process: per-ray figures come from the committed rocprofv3 --pmc passes
-    # over this very command line (tools/collect_profiles.sh -> profiles/r2_pmc_bench.json) x the rays / time measured here.
-    pmc = load_profile("r2_pmc_bench.json")
-    # N > 1: rank 0 traces an interleaved 1/N of the same pixels with the same kernel: the per-ray figures of the N = 1 passes hold
-    use_pmc = pmc if (pmc and (args.scene, args.width, args.height) == ("sponza", 1920, 1080)) else None
-    mix = load_profile("r2_k_trace_instruction_mix.json")
-    if use_pmc and mix and "valu_insts_per_ray" in use_pmc:
-        # vector-ALU issue cycles demanded per second = instructions per ray (PMC) x rays/s (measured here) x average issue cycles of
-        # this kernel's instruction mix, against 1024 SIMDs x 2.4 GHz
-        inst_rate = use_pmc["valu_insts_per_ray"] * kernel_rays_s
-        achieved = inst_rate * mix["avg_issue_cycles_per_inst"] / 1e9
-        roofline.update({"bound": "valu_issue", "achieved": round(achieved, 1), "peak": VALU_PEAK_GCYCLES, "unit": "Gcycle/s",
-                         "frac": round(achieved / VALU_PEAK_GCYCLES, 4), "lane_util": round(use_pmc["lane_util"], 4),
-                         "useful_frac": round(achieved / VALU_PEAK_GCYCLES * use_pmc["lane_util"], 4),
-                         "valu_insts_per_ray": round(use_pmc["valu_insts_per_ray"], 2), "valu_Ginst_s": round(inst_rate / 1e9, 1),
-                         "avg_issue_cycles_per_inst": mix["avg_issue_cycles_per_inst"]})
-        if "vmem_rd_insts_per_ray" in use_pmc:  # the co-limiter: the CU's one vector-memory pipeline (profiles/r2_ablations_k_trace.txt)
-            roofline["vmem_busy_est"] = round(use_pmc["vmem_rd_insts_per_ray"] * kernel_rays_s * mix["vmem_cycles_per_load_inst"] / (256 * 2.4e9), 3)
+    # The PMC counters cannot be read from inside this process: per-ray figures come from the committed rocprofv3 --pmc passes over
+    # this very command line (tools/collect_profiles.sh -> profiles/r3_pmc_bench.json), hash-checked against the device sources of this
+    # tree, x the rays / time measured here.  N > 1: rank 0 traces an interleaved 1/N of the same pixels with the same kernel.
+    pmc, why = counter_figures(PMC_BENCH) if (args.scene, args.width, args.height) == ("sponza", 1920, 1080) else (None, "no committed counter passes for this scene / size")
+    if pmc:
+        roofline.update(valu_roofline(pmc, load_profile(ISSUE_MODEL), kernel_rays_s))
+        roofline.update(traffic_fields(pmc, st["rays"], trace_launches, kernel_rays_s))
+        roofline["note"] = ("BVH (nodes + Woop + index) %.0f MB is L2 / Infinity-Cache resident: alg_frac_of_hbm_peak may exceed 1 and is not a fraction of HBM "
+                            "traffic (traffic = what the counters saw on the fabric).  What binds is vector-ALU issue, the CU's vector-memory pipeline close behind "
+                            "(vmem_busy_est; profiles/r2_ablations_k_trace.txt).  peak = 1024 SIMDs x effective_clock_GHz (GRBM_GUI_ACTIVE / 8 / launch duration of "
+                            "the kernel trace); achieved = SQ_ACTIVE_INST_VALU x 4 cycles per ray (%s) x trace_kernel_Mrays_s of this run; frac >= 1 = saturated "
+                            "(the counter's quanta are 4 cycles).  model_frac_* = SQ_INSTS_VALU per ray x rays/s x the mix's average issue time (profiles/%s: "
+                            "rounded 2/4/4/8 and measured class rates, at the microbenchmark's nominal 2.4 GHz) / 1024 SIMDs.  lane_util = SQ_THREAD_CYCLES_VALU / "
+                            "(64 x SQ_INSTS_VALU)%s"
+                            % (bvh_mb, pmc.get("command", "?"), ISSUE_MODEL, "; per-ray figures of the 1-GPU passes applied to rank 0's shard" if world > 1 else ""))
     else:
-        roofline.update({"bound": "hbm", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4)})
-    if use_pmc and "traffic_bytes_per_ray" in use_pmc:
-        roofline["traffic"] = round(use_pmc["traffic_bytes_per_ray"] * st["rays"] / max(1, trace_launches))
-        roofline["traffic_GBs"] = round(use_pmc["traffic_bytes_per_ray"] * kernel_rays_s / 1e9, 1)
-        roofline["traffic_frac_of_hbm_peak"] = round(use_pmc["traffic_bytes_per_ray"] * kernel_rays_s / 1e9 / HBM_PEAK_GBS, 4)
-        roofline["l2_hit_rate"] = round(use_pmc.get("TCC_hit_rate", 0.0), 3)
-    roofline["note"] = ("BVH (nodes + Woop + index) %.0f MB is L2 / Infinity-Cache resident: most algorithmic bytes never reach HBM (traffic << "
-                        "alg_bytes_per_launch, no re-reads wasted) and alg_frac_of_hbm_peak may exceed 1 — the HBM roof does not bind on this scene "
-                        "(it does on roofline_hbm_resident).  What binds: vector-ALU issue, with the CU's vector-memory pipeline close behind "
-                        "(vmem_busy_est; ablations in profiles/r2_ablations_k_trace.txt).  achieved = PMC SQ_INSTS_VALU per ray (%s) x the kernel's "
-                        "measured rays/s x the average issue cycles of its instruction mix (profiles/r2_k_trace_instruction_mix.json), peak = 1024 SIMDs "
-                        "x 2.4 GHz; lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU): the part of every issued instruction that does work"
-                        % (bvh_mb, (use_pmc or {}).get("command", "no committed PMC file for this configuration") + ("; per-ray figures of the 1-GPU passes applied to rank 0's shard" if use_pmc and world > 1 else "")))
+        roofline.update({"bound": "hbm (algorithmic bytes; the scene is cache resident)", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg_gbs / HBM_PEAK_GBS, 4), "pmc_stale": True,
+                         "note": "no counter figures: " + why + ".  Fallback to SURVEY.md 8d algorithmic bytes / HIP-event time / 8 TB/s, which for this "
+                                 "L2 / Infinity-Cache resident BVH (%.0f MB) can exceed 1 and is not a fraction of HBM traffic" % bvh_mb})
 
     # ---- one frame per call (Instance::Update -> Trace(true), src/Instance.cpp:44-57) with the library's look-ahead ----------
     single = None

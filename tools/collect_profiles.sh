@@ -24,6 +24,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum T
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -- $CMD > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err
 done
 python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
-python3 tools/pmc_profile.py $OUT $OUT/pmc_FETCH_SIZE.json "rocprofv3 --pmc <group> -- $CMD" > $OUT/pmc_profile.json
+python3 tools/pmc_profile.py $OUT $OUT/pmc_FETCH_SIZE.json "rocprofv3 --pmc <group> -- $CMD" $OUT/kernel_trace_phases.json > $OUT/pmc_profile.json
 find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete
 head -8 $OUT/kernel_stats.csv | cut -c1-170; grep -A12 "^k_trace<false" $OUT/pmc_summary.txt; cat $OUT/pmc_profile.json

@@ -5,12 +5,15 @@ HBM / fabric traffic, corrected as MI355X_MICROARCH.md (HBM section) prescribes 
 counts the 128-byte fabric reads of 16-byte-per-lane loads as 64 bytes -> x 1024 x 2; WRITE_SIZE is exact -> x 1024.
 Issue: SQ_INSTS_VALU (wave-instructions) per ray; lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU).
 
-Usage: pmc_profile.py <profile dir> <bench json of one of the passes> "<command>"
+Usage: pmc_profile.py <profile dir> <bench json of one of the passes> "<command>" [kernel_trace_phases.json of the same command]
 Every pass runs the same command, so the k_trace<false, false> launches (warm-up + timed frames) trace config.rays_warmup +
 rays_per_step x steps rays in each pass."""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hash import device_source_hash
 
 root, bench_json, command = sys.argv[1], sys.argv[2], sys.argv[3]
+phases = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
 KERNEL = "k_trace<false, false>"
 
 
@@ -30,6 +33,8 @@ hit, req = per_kernel("TCC_HIT_sum"), per_kernel("TCC_REQ_sum")
 insts, tcyc = per_kernel("SQ_INSTS_VALU"), per_kernel("SQ_THREAD_CYCLES_VALU")
 vmem = per_kernel("SQ_INSTS_VMEM_RD")
 busy, wcyc, gui = per_kernel("SQ_BUSY_CYCLES"), per_kernel("SQ_WAVE_CYCLES"), per_kernel("GRBM_GUI_ACTIVE")
+active_valu = per_kernel("SQ_ACTIVE_INST_VALU")
+N_XCD, N_SIMD = 8, 1024
 traffic = sum(fetch) * 1024 * 2 + sum(write) * 1024
 out = {
     "kernel": KERNEL,
@@ -48,6 +53,20 @@ out = {
     "lane_util": sum(tcyc) / max(1.0, 64.0 * sum(insts)),
     "vmem_rd_insts_per_ray": sum(vmem) / max(1, rays),
     "GRBM_GUI_ACTIVE_per_launch": sum(gui) / max(1, len(gui)),
+    "traffic_bytes_per_ray_uncorrected": (sum(fetch) * 1024 + sum(write) * 1024) / max(1, rays),
+    "SQ_ACTIVE_INST_VALU_per_launch": sum(active_valu) / max(1, len(active_valu)),
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = the launch's duration in shader-clock cycles
+    "cycles_per_launch": sum(gui) / max(1, len(gui)) / N_XCD,
+    # fraction of all SIMD cycles of the launch in which a vector-ALU instruction was executing: SQ_ACTIVE_INST_VALU counts in units of 4 cycles
+    "valu_busy_frac": (sum(active_valu) * 4.0) / max(1.0, N_SIMD * sum(gui) / N_XCD),
+    "cycles_per_valu_inst_per_simd": (N_SIMD * sum(gui) / N_XCD) / max(1.0, sum(insts)),
+    "source_hash": device_source_hash(),
     "note": "fabric-side bytes (Infinity-Cache hits are counted, MI355X_MICROARCH.md)",
 }
+if phases:
+    key = "timed_avg_launch_ms"
+    if key in phases:
+        out["avg_launch_ms_kernel_trace"] = phases[key]
+        # the timed launches are the last ones of the process; the counters average over warm-up + timed launches of the same sizes
+        out["effective_clock_GHz"] = out["cycles_per_launch"] / (phases[key] * 1e-3) / 1e9
 print(json.dumps(out, indent=1))
