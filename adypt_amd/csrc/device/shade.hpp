@@ -12,14 +12,17 @@
 // atomics/us on this chip), and one atomic per workgroup appends the survivors.  Segment s owns the slot range
 // [s * seg_cap, (s+1) * seg_cap).  None of this affects results — per-pixel work is independent of slot order.
 //
-// Queue layout (SoA of float4, slot-indexed, rewritten compacted every bounce):
-//   ray_o = (origin.xyz, tmin)      ray_d = (dir.xyz, bits(local pixel))      <- the 32 B the traversal reads
-//   col   = (throughput rgb, -)     rad   = (radiance so far rgb, -)          <- carried by the shade kernel only
-//   hit   = (bits(scene triangle id), u, v, t)                                 <- the 16 B the traversal writes
+// Queue layout (SoA, slot-indexed, rewritten compacted every bounce) — 52 B per path and bounce (round 2: 64 B):
+//   ray_o = origin.xyz (12 B; tmin is the pass's)   ray_d = (dir.xyz, path word) (16 B)   <- the 28 B the traversal reads
+//   col   = throughput rgb (12 B)                                                          <- carried by the shade kernel only
+//   hit   = (bits(scene triangle id), u, v) (12 B)                                         <- what the traversal writes
+//   path word: bits 30..0 path id (batch frame * local pixels + local pixel), bit 31 "radiance parked in done[path id]"
+// (adypt_trace_rays batches and the sun-visibility queue keep float4 records: per-ray tmin in ray_o.w, t in hit.w)
 // Per-local-pixel buffers (block-major, 32x32 blocks of 16 8x8 wave tiles): accum (RGBA32F running mean),
 // cache (primary hit: bits(tri), u, v, -), shift (2 bytes).
-// Scene triangles are repacked at upload from the 100-byte Triangle (src/Util/Shape.hpp:70-74) to 112 bytes =
-// 7 x float4: [p0 p1 p2 n0 n1 n2 | matid | pad] (5 x 16 B, always read) + [tc0 tc1 tc2 | pad] (2 x 16 B, textured only).
+// Scene triangles are repacked at upload from the 100-byte Triangle (src/Util/Shape.hpp:70-74) to 128 bytes =
+// 8 x float4: [p0 p1 p2 n0 n1 n2 | matid | pad] (5 x 16 B, always read) + [tc0 tc1 tc2 | pad] (2 x 16 B, textured only) + 16 B pad:
+// one 128-byte line per gather (at 112 bytes a record straddled two lines three times out of four).
 #pragma once
 #include "canon_math.hpp"
 
@@ -33,7 +36,9 @@ constexpr int kLdsStackMax = 8;                // stack entries kept in LDS per 
 constexpr int kNumSegments = 8;                // one ray-queue segment per XCD
 constexpr int kCursorStride = 32;              // uint32 words between per-segment counters: one 128-byte line each
 constexpr int kShadeThreads = 256;             // workgroup of the gen / shade / viewer kernels = one queue chunk
-constexpr int kTriFloat4 = 7;                  // device triangle record: 7 x float4
+constexpr int kTriFloat4 = 8;                  // device triangle record: 8 x float4 = one 128-byte line
+constexpr uint32_t kPathParked = 0x80000000u;  // path word: the path's radiance so far is parked in FrameArgs::done[path id]
+constexpr uint32_t kPathIdMask = 0x7fffffffu;
 
 struct DeviceStats {                           // accumulated until adypt_reset_stats
 	unsigned long long rays, nodes, tris, hits, shaded, overflows, bad_materials;
@@ -47,8 +52,8 @@ struct TraceArgs {
 	const uint4 *nodes;
 	const float4 *woop;
 	const int32_t *tri_indices;
-	const float4 *ray_o, *ray_d;
-	float4 *hit;
+	const float4 *ray_o, *ray_d;   // packed: ray_o is 3 floats per slot and tmin is the pass's; otherwise (origin, tmin) per slot
+	float4 *hit;                   // packed: 3 floats per slot (bits(tri), u, v); otherwise (bits(tri), u, v, t)
 	RayStats *ray_stats;           // STATS only (may be null)
 	const uint32_t *count;         // rays per segment: count[s * kCursorStride] (device memory)
 	uint32_t *cursor;              // fetch cursor per segment: cursor[s * kCursorStride], zero at launch
@@ -57,6 +62,8 @@ struct TraceArgs {
 	uint32_t seg_cap;              // slots per segment
 	int32_t stack_size, lds_depth;
 	uint32_t refill_min, chunk;    // tunables of the persistent fetch (traverse.hpp)
+	uint32_t packed;               // the path tracer's own queues (12-byte origins and hits) / float4 records
+	float tmin;                    // packed: tmin of every ray of the pass
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -90,9 +97,9 @@ struct SceneArgs {
 };
 
 struct QueueArgs {
-	float4 *ray_o, *ray_d, *col;   // queue being read (shade) / written (gen); col.w != 0 <=> the path has radiance parked
-	float4 *hit;                   //   in FrameArgs::done[path] (emission picked up so far) — it does not travel in the queue
-	float4 *out_o, *out_d, *out_col;
+	float *ray_o; float4 *ray_d; float *col; // queue being read (shade) / written (gen): 3 floats, float4, 3 floats per slot
+	float *hit;                    // 3 floats per slot
+	float *out_o; float4 *out_d; float *out_col;
 	const uint32_t *count_in;      // [s * kCursorStride]
 	uint32_t *count_out;           // [s * kCursorStride]
 	uint32_t seg_cap;              // allocated slots per segment: segment s owns [s * seg_cap, (s + 1) * seg_cap)
@@ -134,6 +141,11 @@ __device__ __forceinline__ bool local_pixel_xy(const FrameArgs &f, const int32_t
 	*y = by * kBlockDim + (wt >> 2) * 8 + (ln >> 3);
 	return *x < f.width && *y < f.height;
 }
+
+// 12-byte records (one global_load_dwordx3 / global_store_dwordx3 each)
+struct __attribute__((packed, aligned(4))) Rec3 { float x, y, z; };
+__device__ __forceinline__ F3 ld3(const float *base, size_t i) { const Rec3 r = *(const Rec3 *)(base + 3 * i); return f3(r.x, r.y, r.z); }
+__device__ __forceinline__ void st3(float *base, size_t i, float x, float y, float z) { Rec3 r; r.x = x; r.y = y; r.z = z; *(Rec3 *)(base + 3 * i) = r; }
 
 // tmpLifetime group of batch frame `frame`, relative to the group of the batch's first frame (f.spp)
 __device__ __forceinline__ int frame_group(const FrameArgs &f, int frame) { return (f.spp + frame) / f.tmp_life - f.spp / f.tmp_life; }
@@ -217,10 +229,10 @@ __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, Scen
 	const uint32_t slot = append_slot(alive, q.count_out + seg * kCursorStride, seg * q.seg_cap);
 	if(!alive) return;
 	const F3 d = camera_dir(f, x, y, bx, by);
-	q.out_o[slot] = make_float4(f.origin[0], f.origin[1], f.origin[2], f.tmin);
-	q.out_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(frame * f.n_local_px + L)); // path id (batch frame, local pixel)
-	q.out_col[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-	if(use_cache) q.hit[slot] = cache_of_group(f, px, frame_group(f, frame))[L];
+	st3(q.out_o, slot, f.origin[0], f.origin[1], f.origin[2]);
+	q.out_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(frame * f.n_local_px + L)); // path word: id (batch frame, local pixel), nothing parked
+	st3(q.out_col, slot, 1.0f, 1.0f, 1.0f);
+	if(use_cache) { const float4 h = cache_of_group(f, px, frame_group(f, frame))[L]; st3(q.hit, slot, h.x, h.y, h.z); }
 }
 
 // Batches of several frames: the frames that re-trace their primary rays (spp % tmpLife == 0) run a primary-only
@@ -232,8 +244,8 @@ __global__ __launch_bounds__(kShadeThreads) void k_store_cache(FrameArgs f, Queu
 	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
 	if(local >= q.count_in[seg * kCursorStride]) return;
 	const uint32_t slot = seg * q.seg_cap + local;
-	const float4 h = q.hit[slot];
-	const uint32_t pi = (uint32_t)__float_as_int(q.ray_d[slot].w); // path id: (batch frame, local pixel)
+	const F3 h = ld3(q.hit, slot);
+	const uint32_t pi = __float_as_uint(q.ray_d[slot].w) & kPathIdMask; // path id: (batch frame, local pixel)
 	const int frame = (int)(pi / (uint32_t)f.n_local_px), L = (int)(pi % (uint32_t)f.n_local_px);
 	cache_of_group(f, px, frame_group(f, frame))[L] = make_float4(h.x, h.y, h.z, 0.0f);
 }
@@ -349,10 +361,8 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 
 // One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for every live path.
 // store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
-// WAVES = waves per SIMD the register budget is set for: 7 (72 VGPRs) is the fastest when the kernel has the GPU to itself; 8 (64
-// VGPRs, a few spills) lets two workgroups instead of one sit next to a running traversal launch of another pipe.
-template <int WAVES>
-__global__ __launch_bounds__(kShadeThreads, WAVES) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, ShadowArgs sh, int b, int store_cache, int count_stats)
+// 7 waves per SIMD (72 VGPRs): measured optimum (6: -2.4 %, 8 needs spills: +19 % kernel time; profiles/r2_ablations_k_trace.txt)
+__global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, ShadowArgs sh, int b, int store_cache, int count_stats)
 {
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	const uint32_t n_in = q.count_in[seg * kCursorStride];
@@ -367,9 +377,11 @@ __global__ __launch_bounds__(kShadeThreads, WAVES) void k_shade(FrameArgs f, Sce
 	F3 ret_in = f3(0, 0, 0);
 	if(alive)
 	{
-		const float4 rd = q.ray_d[slot_in], h = q.hit[slot_in], c4 = q.col[slot_in];
+		const float4 rd = q.ray_d[slot_in];
+		const F3 h = ld3(q.hit, slot_in);
+		color = ld3(q.col, slot_in);
 		dir = f3(rd.x, rd.y, rd.z);
-		pi = __float_as_int(rd.w);
+		pi = (int)(__float_as_uint(rd.w) & kPathIdMask);
 		L = pi;
 		if(f.batched)
 		{
@@ -377,10 +389,9 @@ __global__ __launch_bounds__(kShadeThreads, WAVES) void k_shade(FrameArgs f, Sce
 			L = pi - frame * f.n_local_px;
 			sobol += frame * 64;
 		}
-		color = f3(c4.x, c4.y, c4.z);
 		// radiance picked up so far: zero for almost every path, so it is parked per path (FrameArgs::done[pi]) and only
 		// touched when it changes, instead of being read and re-written (32 B) by every bounce of every path
-		parked = c4.w != 0.0f;
+		parked = (__float_as_uint(rd.w) & kPathParked) != 0u;
 		if(parked) { const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); }
 		ret_in = ret;
 		const int tri_idx = __float_as_int(h.x);
@@ -496,23 +507,23 @@ __global__ __launch_bounds__(kShadeThreads, WAVES) void k_shade(FrameArgs f, Sce
 	const uint32_t slot = append_slot(alive, q.count_out + seg * kCursorStride, seg * q.seg_cap);
 	if(alive)
 	{
-		q.out_o[slot] = make_float4(origin.x, origin.y, origin.z, f.tmin);
-		q.out_d[slot] = make_float4(dir.x, dir.y, dir.z, __int_as_float(pi));
+		st3(q.out_o, slot, origin.x, origin.y, origin.z);
 		if(__float_as_uint(ret.x) != __float_as_uint(ret_in.x) || __float_as_uint(ret.y) != __float_as_uint(ret_in.y) ||
 		   __float_as_uint(ret.z) != __float_as_uint(ret_in.z))
 		{
 			f.done[pi] = make_float4(ret.x, ret.y, ret.z, 0.0f);
 			parked = true;
 		}
-		q.out_col[slot] = make_float4(color.x, color.y, color.z, parked ? 1.0f : 0.0f);
+		q.out_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)pi | (parked ? kPathParked : 0u)));
+		st3(q.out_col, slot, color.x, color.y, color.z);
 	}
 	if(sh.enabled) // (kernel argument: uniform branch around the barriers of append_slot)
 	{
 		const uint32_t sslot = append_slot(escaped, sh.count + seg * kCursorStride, seg * q.seg_cap);
 		if(escaped)
 		{
-			const float4 ro = q.ray_o[slot_in]; // the position the path escaped from (camera or last hit), tmin
-			sh.o[sslot] = ro;
+			const F3 ro = ld3(q.ray_o, slot_in); // the position the path escaped from (camera or last hit)
+			sh.o[sslot] = make_float4(ro.x, ro.y, ro.z, f.tmin);
 			sh.d[sslot] = make_float4(sh.dir[0], sh.dir[1], sh.dir[2], __int_as_float(pi));
 			sh.col[sslot] = make_float4(color.x, color.y, color.z, parked ? 1.0f : 0.0f);
 		}
@@ -546,7 +557,8 @@ __global__ __launch_bounds__(kShadeThreads) void k_viewer(FrameArgs f, SceneArgs
 	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
 	if(local >= n_in) return;
 	const uint32_t slot = seg * q.seg_cap + local;
-	const float4 rd = q.ray_d[slot], h = q.hit[slot];
+	const float4 rd = q.ray_d[slot];
+	const F3 h = ld3(q.hit, slot);
 	const int L = __float_as_int(rd.w);
 	const int tri_idx = __float_as_int(h.x);
 	const float u = h.y, v = h.z;

@@ -116,7 +116,6 @@ struct adypt_ctx {
 	// launch geometry of the persistent traversal kernel
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0, occupancy_api = 0;
 	uint32_t refill_min = kRefillMin, chunk = kChunk;
-	int shade_waves = 7;       // register budget variant of k_shade (tuning: ADYPT_SHADE_WAVES = 7 | 8)
 
 	// state
 	adypt_pt_params params{}, pending{};
@@ -294,14 +293,26 @@ int configure_trace(adypt_ctx *c, int stack_size)
 }
 
 int launch_trace(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int parity, const uint32_t *count, uint32_t *cursor, int stack_size, bool stats,
-				 RayStats *ray_stats, bool any_hit = false, bool shadow_queue = false)
+				 RayStats *ray_stats, bool any_hit = false, bool shadow_queue = false, bool packed = false)
 {
 	TraceArgs a;
 	a.nodes = (const uint4 *)c->d_nodes;
 	a.woop = (const float4 *)c->d_woop;
 	a.tri_indices = (const int32_t *)c->d_tri_indices;
-	a.ray_o = (shadow_queue ? c->sh_o : c->q_o[parity]) + win.offset; a.ray_d = (shadow_queue ? c->sh_d : c->q_d[parity]) + win.offset;
-	a.hit = (shadow_queue ? c->sh_hit : c->d_hit) + win.offset;
+	// the path tracer's own queues hold 12-byte origins and hits (shade.hpp); ray batches handed in by the caller and the sun-visibility
+	// queue are float4 records.  The buffers are allocated 16 bytes per slot either way; a window starts 3 (or 4) floats x offset in.
+	a.packed = packed ? 1u : 0u; a.tmin = c->params.ray_tmin;
+	if(packed)
+	{
+		a.ray_o = (const float4 *)((const float *)c->q_o[parity] + 3 * win.offset);
+		a.hit = (float4 *)((float *)c->d_hit + 3 * win.offset);
+		a.ray_d = c->q_d[parity] + win.offset;
+	}
+	else
+	{
+		a.ray_o = (shadow_queue ? c->sh_o : c->q_o[parity]) + win.offset; a.ray_d = (shadow_queue ? c->sh_d : c->q_d[parity]) + win.offset;
+		a.hit = (shadow_queue ? c->sh_hit : c->d_hit) + win.offset;
+	}
 	a.ray_stats = ray_stats;
 	a.count = count; a.cursor = cursor;
 	a.spill = pipe.spill;
@@ -373,9 +384,9 @@ QueueArgs queue_args(adypt_ctx *c, const QueueWindow &win, int in, const uint32_
 {
 	QueueArgs q;
 	q.seg_paths = frames > 0 ? pass_seg_paths(c, win, frames) : win.seg_cap;
-	q.ray_o = c->q_o[in] + win.offset; q.ray_d = c->q_d[in] + win.offset; q.col = c->q_col[in] + win.offset;
-	q.hit = c->d_hit + win.offset;
-	q.out_o = c->q_o[in ^ 1] + win.offset; q.out_d = c->q_d[in ^ 1] + win.offset; q.out_col = c->q_col[in ^ 1] + win.offset;
+	q.ray_o = (float *)c->q_o[in] + 3 * win.offset; q.ray_d = c->q_d[in] + win.offset; q.col = (float *)c->q_col[in] + 3 * win.offset;
+	q.hit = (float *)c->d_hit + 3 * win.offset;
+	q.out_o = (float *)c->q_o[in ^ 1] + 3 * win.offset; q.out_d = c->q_d[in ^ 1] + win.offset; q.out_col = (float *)c->q_col[in ^ 1] + 3 * win.offset;
 	q.count_in = count_in; q.count_out = count_out;
 	q.seg_cap = win.seg_cap;
 	return q;
@@ -621,7 +632,6 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	c->num_cus = prop.multiProcessorCount;
 	if(const char *ov = getenv("ADYPT_REFILL_MIN")) c->refill_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
-	if(const char *ov = getenv("ADYPT_SHADE_WAVES")) c->shade_waves = atoi(ov) == 8 ? 8 : 7;
 
 	c->n_nodes = d->n_nodes; c->n_refs = d->n_refs; c->n_tris = d->n_tris; c->n_mats = d->n_mats; c->n_tex = d->n_textures;
 	c->width = d->width; c->height = d->height; c->rank = d->tile_rank; c->nranks = d->tile_nranks;
@@ -869,7 +879,7 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 		hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 0);
 		end_timing(stop, c->stream);
 	}
-	r = launch_trace(c, pipe, win, 0, ctr->count[0], ctr->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr);
+	r = launch_trace(c, pipe, win, 0, ctr->count[0], ctr->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr, false, false, true);
 	if(r != ADYPT_OK) return r;
 	{
 		QueueArgs q = queue_args(c, win, 0, ctr->count[0], ctr->count[1], 1);
@@ -993,7 +1003,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			hipEvent_t *stop = begin_timing(c, 1, c->stream);
 			hipLaunchKernelGGL(k_gen_primary, dim3(grid_r), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 1);
 			end_timing(stop, c->stream);
-			int r = launch_trace(c, pipe, win, 0, ctr->count[0], ctr->cursor[0], c->params.stack_size, stats, nullptr);
+			int r = launch_trace(c, pipe, win, 0, ctr->count[0], ctr->cursor[0], c->params.stack_size, stats, nullptr, false, false, true);
 			if(r != ADYPT_OK) return r;
 			QueueArgs q2 = queue_args(c, win, 0, ctr->count[0], ctr->count[1], n_retrace);
 			stop = begin_timing(c, 1, c->stream);
@@ -1037,7 +1047,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 				FrameCounters *ctr = pipe.counters;
 				if(!(b == 0 && use_cache))
 				{
-					int r = launch_trace(c, pipe, sub[k].win, in, ctr->count[b], ctr->cursor[b], c->params.stack_size, stats, nullptr);
+					int r = launch_trace(c, pipe, sub[k].win, in, ctr->count[b], ctr->cursor[b], c->params.stack_size, stats, nullptr, false, false, true);
 					if(r != ADYPT_OK) return r;
 				}
 				QueueArgs q = queue_args(c, sub[k].win, in, ctr->count[b], ctr->count[b + 1], sub[k].f.n_frames);
@@ -1047,8 +1057,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 				memcpy(sh.dir, c->sun_dir, sizeof(sh.dir));
 				sh.enabled = c->sun_visibility;
 				hipEvent_t *stop = begin_timing(c, 1, pipe.stream);
-				if(c->shade_waves == 8) hipLaunchKernelGGL(k_shade<8>, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, sh, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
-				else hipLaunchKernelGGL(k_shade<7>, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, sh, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
+				hipLaunchKernelGGL(k_shade, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, sh, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
 				end_timing(stop, pipe.stream);
 				if(c->sun_visibility)
 				{

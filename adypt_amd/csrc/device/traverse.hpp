@@ -153,10 +153,16 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			const bool take = !active && my_rank < got;
 			const uint32_t new_ray = begin + my_rank;
 			float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 1, 0);
-			if(take) { ro = a.ray_o[new_ray]; rd = a.ray_d[new_ray]; }
+			if(take)
+			{
+				if(a.packed) { const F3 o3 = ld3((const float *)a.ray_o, new_ray); ro = make_float4(o3.x, o3.y, o3.z, a.tmin); }
+				else ro = a.ray_o[new_ray];
+				rd = a.ray_d[new_ray];
+			}
 			if(flush)
 			{
-				a.hit[ray] = make_float4(__int_as_float(flush_tri), hit_u, hit_v, hit_t);
+				if(a.packed) st3((float *)a.hit, ray, __int_as_float(flush_tri), hit_u, hit_v);
+				else a.hit[ray] = make_float4(__int_as_float(flush_tri), hit_u, hit_v, hit_t);
 				flush = false;
 			}
 			if(take)
@@ -408,7 +414,8 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 	if(flush) // rays finished after the queue ran dry
 	{
 		const int32_t tri_id = hit_idx != -1 ? a.tri_indices[hit_idx] : -1;
-		a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
+		if(a.packed) st3((float *)a.hit, ray, __int_as_float(tri_id), hit_u, hit_v);
+		else a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
 	}
 	ADYPT_MEASURE_WAVE_END(a.stats);
 	if(any_overflow) atomicAdd(&a.stats->overflows, 1ull);
