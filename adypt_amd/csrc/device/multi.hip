@@ -10,6 +10,7 @@
 // librccl is loaded with dlopen on first use: the library has no link-time dependency on it, and a process that already
 // holds an RCCL (e.g. the copy PyTorch ships) shares that one instead of bringing a second.
 #include "ctx_access.hpp"
+#include "host_transport.hpp"
 #include "../../../include/adypt_hip.h"
 
 #include <dlfcn.h>
@@ -50,6 +51,18 @@ RcclApi *rccl(std::string *err)
 {
 	std::lock_guard<std::mutex> lock(g_rccl_mutex);
 	if(g_rccl.handle) return &g_rccl;
+	if(const char *tr = getenv("ADYPT_COMM_TRANSPORT"))
+		if(!strcmp(tr, "host"))
+		{	// TEST HOOK (host_transport.hpp): the same calls, carried through shared memory, so that N ranks can share one device
+			namespace ht = adypt_host_transport;
+			RcclApi a;
+			a.handle = (void *)&g_rccl; a.path = "host transport (test hook)";
+			a.GetUniqueId = ht::GetUniqueId; a.CommInitRank = ht::CommInitRank; a.CommInitAll = ht::CommInitAll; a.CommDestroy = ht::CommDestroy;
+			a.Send = ht::Send; a.Recv = ht::Recv; a.AllReduce = ht::AllReduce; a.GroupStart = ht::GroupStart; a.GroupEnd = ht::GroupEnd;
+			a.GetErrorString = ht::GetErrorString;
+			g_rccl = a;
+			return &g_rccl;
+		}
 	std::vector<std::pair<std::string, int>> tries;
 	if(const char *ov = getenv("ADYPT_RCCL_LIB")) tries.push_back({ov, RTLD_NOW | RTLD_LOCAL});
 	tries.push_back({"librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD});

@@ -333,6 +333,10 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     gather_ms = (time.perf_counter() - t_gather) * 1e3
     st = pt.GetStats()
+    # per-rank breakdown, so that a scaling run can be diagnosed from its own line: every rank fills its own slots, one sum all-reduce
+    # hands every rank the whole table (5 x N doubles)
+    mine = [elapsed * 1e3, float(st["trace_ms"]), float(st["shade_ms"]), gather_ms, float(st["rays"])]
+    per_rank = None
     if use_torch:
         if image is not None and on_device:
             image = image.cpu().numpy()
@@ -342,8 +346,15 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         elapsed, total_rays = float(tt.item()), int(rays.item())
+        table = torch.zeros(5 * world, dtype=torch.float64, device=red_dev)
+        table[5 * rank:5 * rank + 5] = torch.tensor(mine, dtype=torch.float64)
+        dist.all_reduce(table, op=dist.ReduceOp.SUM)
+        per_rank = table.cpu().numpy().reshape(world, 5)
     else:
         if world > 1:
+            flat = [0.0] * (5 * world)
+            flat[5 * rank:5 * rank + 5] = mine
+            per_rank = np.array(pt.CommAllReduce(flat, "sum")).reshape(world, 5)
             elapsed = pt.CommAllReduce([elapsed], "max")[0]          # MAX over ranks
             total_rays = int(round(pt.CommAllReduce([float(st["rays"])], "sum")[0]))  # exact: < 2^53
         else:
@@ -433,10 +444,17 @@ def main() -> None:
                "config": {"workload": "%s-like procedural stand-in (%s), %d triangles, %dx%d, full wavefront path trace, maxBounce %d, tmpLifetime %d, 1 spp per step; one radiance gather per run"
                                       % (args.scene, spec.label, inst.scene.n_tris, c.width, c.height, c.max_bounce, c.tmp_lifetime),
                           "rays_per_step": round(total_rays / max(1, args.steps)), "tile_shard": "32x32 blocks, owner (bx+by) mod N",
-                          "frames_in_flight": fif, "rays_warmup": rays_warmup, "comm": ("torch.distributed" if use_torch else "native RCCL") if world > 1 else "none",
+                          "frames_in_flight": fif, "rays_warmup": rays_warmup, "comm": ("torch.distributed" if use_torch else ("host-staged TEST transport (ADYPT_COMM_TRANSPORT=host: not a measurement)" if os.environ.get("ADYPT_COMM_TRANSPORT") == "host" else "native RCCL")) if world > 1 else "none",
                           "setup_s": round(t_setup, 2)},
                "roofline": roofline, "roofline_hbm_resident": hbm, "cpu_baseline": cpu, "single_frame": single,
                "gather_ms": round(gather_ms, 3), "shade_kernels_ms": round(shade_ms, 2), "trace_kernels_ms": round(trace_ms, 2),
+               "per_rank": None if per_rank is None else {
+                   "wall_ms": [round(float(v), 3) for v in per_rank[:, 0]], "trace_kernels_ms": [round(float(v), 3) for v in per_rank[:, 1]],
+                   "other_kernels_ms": [round(float(v), 3) for v in per_rank[:, 2]], "gather_ms": [round(float(v), 3) for v in per_rank[:, 3]],
+                   "rays": [int(v) for v in per_rank[:, 4]],
+                   # share of a rank's wall time not inside a tracing kernel or the gather: launch tails show up in the kernels, host gaps here
+                   "outside_kernels_frac": [round(float(1.0 - (r[1] + r[2] + r[3]) / max(r[0], 1e-9)), 3) for r in per_rank],
+                   "note": "wall = this rank's timed region (K steps + its part of the gather); rank 0's gather includes waiting for the slowest peer"},
                "image_mean": float(image.mean()) if image is not None else None}
         print(json.dumps(out))
         sys.stdout.flush()

@@ -3,8 +3,12 @@ has ONE card, and RCCL refuses two ranks on one device, so what can run here is 
 point — RCCL is loaded, a communicator is created on the device, the gather / un-tiling / read-back path and the control-plane
 helpers run — plus the argument checking.  The N > 1 shard geometry the gather relies on is covered by the tile-shard tests
 (test_gpu_parity.py, test_gpu_large.py) and the world-2 CPU test (test_distributed_cpu.py)."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -123,3 +127,18 @@ def test_multi_fan_out_on_one_device(name, w, h, n_dev, scene_cache, sobol_matri
     with pytest.raises(N.AdyptError):
         m.CommInit()  # no communicator in this mode
     m.destroy()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 160, 96), (3, 100, 75), (4, 64, 36)])
+def test_process_per_gpu_gather_with_world_greater_than_one(world, w, h):
+    """adypt_comm_* with world = 2, 3, 4 PROCESSES on the one device: the same code path as over RCCL (counts per rank, strides, grouped
+    send / receive enqueued on the contexts' streams behind the tracing kernels, un-tiling on the root, all-reduce, barrier), the bytes
+    carried by the host-staged test transport instead (ADYPT_COMM_TRANSPORT=host: RCCL refuses two ranks on one device).  Rank 0's
+    assembled image must equal the one-context image bit for bit, twice in a row; (4, 64 x 36) includes a rank that owns no block.
+    The ranks are started by a launcher process that never touches the GPU (tools/comm_world.py)."""
+    import json, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "comm_world.py"), "launch", str(world), "tiny0", str(w), str(h), "5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert out["ok"] and out["world"] == world and out["pixels_that_differ_from_the_one_context_image"] == [0, 0], out
