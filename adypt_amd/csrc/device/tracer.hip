@@ -640,7 +640,14 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	c->n_local_blocks = (int)c->local_blocks.size();
 	c->n_local_px = c->n_local_blocks * kBlockPixels;
 
+#ifdef ADYPT_MEASURE_FP16_NODES // measurement-only build (csrc/measure/k_trace_ablations.hpp): 128-byte nodes with binary16 bounds
+	{
+		const std::vector<uint8_t> wide = adypt::nodes_as_fp16((const uint8_t *)d->nodes, (size_t)d->n_nodes);
+		TRY_CREATE(upload(c, &c->d_nodes, wide.data(), wide.size()));
+	}
+#else
 	TRY_CREATE(upload(c, &c->d_nodes, (const uint8_t *)d->nodes, (size_t)d->n_nodes * 80));
+#endif
 	TRY_CREATE(upload(c, &c->d_tri_indices, d->tri_indices, (size_t)d->n_refs));
 	{
 		std::vector<float> woop;

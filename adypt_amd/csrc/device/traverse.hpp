@@ -31,6 +31,10 @@
 #define ADYPT_MEASURE_AFTER_NODE_LOADS(np, lane)
 #define ADYPT_MEASURE_AFTER_SLAB_TEST(aox, aoy, aoz, aix, aiy)
 #endif
+#ifndef ADYPT_MEASURE_FP16_NODES
+#define ADYPT_MEASURE_MORE_NODE_REGS()
+#define ADYPT_MEASURE_LOAD_MORE_NODE(np)
+#endif
 #ifndef ADYPT_MEASURE_WAVE_TIMELINE
 #define ADYPT_MEASURE_WAVE_BEGIN()
 #define ADYPT_MEASURE_WAVE_FIRST_RAYS()
@@ -42,6 +46,9 @@ namespace adypt {
 
 constexpr int kRefillMin = 16; // default: refill when at least this many lanes of the wave are idle (or all are)
 constexpr int kChunk = 128;    // default: rays reserved per queue atomic
+#ifndef ADYPT_MEASURE_FP16_NODES
+constexpr int kNodeUint4 = 5;  // the 80-byte WideBVHNode, verbatim (src/BVH/WideBVH.hpp:13-26)
+#endif
 
 // Reserve up to `want` consecutive rays: first from the segment of "our" XCD (blockIdx & 7 groups the workgroups
 // that share an L2 under the observed round-robin dispatch — a speed hint only), then steal from the others.
@@ -292,14 +299,16 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 			}
 			uint4 n0, n1, n2, n3, n4;
 			ADYPT_DEF4(n0); ADYPT_DEF4(n1); ADYPT_DEF4(n2); ADYPT_DEF4(n3); ADYPT_DEF4(n4);
+			ADYPT_MEASURE_MORE_NODE_REGS();
 			// The pending node is fetched in the trip that will slab-test it, i.e. once this trip's pair leaves no triangle behind.
 			// A lane that still has triangles after the pair used to fetch its node again every trip (an L1 hit, but the vector
 			// memory pipeline is as loaded as the vector ALU here — tools/microbench/l1_patterns.hip: a 16-byte-per-lane load costs
 			// 16 cycles per CU at best and ~0.6 cycle per distinct cache line beyond that).
 			if(pending && tg_y == 0)
 			{
-				const uint4 *np = a.nodes + (size_t)node * 5;
+				const uint4 *np = a.nodes + (size_t)node * kNodeUint4;
 				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
+				ADYPT_MEASURE_LOAD_MORE_NODE(np);
 				ADYPT_MEASURE_AFTER_NODE_LOADS(np, lane);
 			}
 			__builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting arithmetic between the load issues
@@ -354,6 +363,9 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 				ng_x = n1.x;
 				tg_x = n1.y;
 				uint32_t hitmask = 0;
+#ifdef ADYPT_MEASURE_FP16_NODES
+				hitmask = slab_test_fp16_nodes(n1, n2, n3, n4, n5, n6, n7, nx, ny, nz, octinv4, aix, aiy, aiz, aox, aoy, aoz, tmin, hit_t);
+#else
 #pragma unroll
 				for(int g = 0; g < 2; ++g)
 				{
@@ -382,6 +394,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 						if(cmin <= cmax) hitmask |= ((child_bits4 >> sh) & 0xffu) << ((bit_index4 >> sh) & 0xffu);
 					}
 				}
+#endif
 				ADYPT_MEASURE_AFTER_SLAB_TEST(aox, aoy, aoz, aix, aiy);
 				ng_y = (hitmask & 0xff000000u) | (head_w >> 24);
 				tg_y = hitmask & 0x00ffffffu;
