@@ -61,7 +61,7 @@ struct TraceArgs {
 	DeviceStats *stats;
 	uint32_t seg_cap;              // slots per segment
 	int32_t stack_size, lds_depth;
-	uint32_t refill_min, chunk;    // tunables of the persistent fetch (traverse.hpp)
+	uint32_t refill_min, chunk, bite, endgame; // tunables of the persistent fetch (traverse.hpp)
 	uint32_t packed;               // the path tracer's own queues (12-byte origins and hits) / float4 records
 	float tmin;                    // packed: tmin of every ray of the pass
 };

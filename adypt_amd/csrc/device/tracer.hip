@@ -115,7 +115,7 @@ struct adypt_ctx {
 
 	// launch geometry of the persistent traversal kernel
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0, occupancy_api = 0;
-	uint32_t refill_min = kRefillMin, chunk = kChunk;
+	uint32_t refill_min = kRefillMin, chunk = kChunk, bite = kBite, endgame = kEndgame;
 
 	// state
 	adypt_pt_params params{}, pending{};
@@ -274,7 +274,7 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	c->lds_depth = std::max(1, std::min(stack_size, kLdsStackMax));
 	// testing / tuning hook: a smaller LDS part pushes stack entries into the global spill array (tests cover that path)
 	if(const char *ov = getenv("ADYPT_LDS_STACK_DEPTH")) c->lds_depth = std::max(1, std::min(c->lds_depth, atoi(ov)));
-	size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2);
+	size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2) + sizeof(WgPool); // stacks + the workgroup's ray pool
 	int per_cu = 0;
 	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
 	c->occupancy_api = per_cu;
@@ -318,7 +318,7 @@ int launch_trace(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int par
 	a.spill = pipe.spill;
 	a.stats = c->d_stats;
 	a.seg_cap = win.seg_cap;
-	a.refill_min = c->refill_min; a.chunk = c->chunk;
+	a.refill_min = c->refill_min; a.chunk = c->chunk; a.bite = c->bite; a.endgame = c->endgame;
 	a.stack_size = stack_size; a.lds_depth = c->lds_depth;
 	const size_t lds = c->lds_bytes;
 	hipEvent_t *stop = begin_timing(c, 0, pipe.stream);
@@ -632,6 +632,8 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	c->num_cus = prop.multiProcessorCount;
 	if(const char *ov = getenv("ADYPT_REFILL_MIN")) c->refill_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
+	if(const char *ov = getenv("ADYPT_ENDGAME")) c->endgame = (uint32_t)std::max(0, std::min(1024, atoi(ov)));
+	if(const char *ov = getenv("ADYPT_BITE")) c->bite = (uint32_t)std::max(1, std::min(4096, atoi(ov)));
 
 	c->n_nodes = d->n_nodes; c->n_refs = d->n_refs; c->n_tris = d->n_tris; c->n_mats = d->n_mats; c->n_tex = d->n_textures;
 	c->width = d->width; c->height = d->height; c->rank = d->tile_rank; c->nranks = d->tile_nranks;

@@ -45,7 +45,10 @@
 namespace adypt {
 
 constexpr int kRefillMin = 16; // default: refill when at least this many lanes of the wave are idle (or all are)
-constexpr int kChunk = 128;    // default: rays reserved per queue atomic
+constexpr int kChunk = 128;    // default: rays a workgroup reserves per queue atomic
+constexpr int kBite = 32;      // default: rays a wave takes from its workgroup's reservation at a time (end of a launch)
+constexpr int kEndgame = 4;    // default: the end of a launch = fewer than this many more chunks per wave left in the segment
+struct WgPool { unsigned long long range; uint32_t lock, dry; }; // range = (end << 32) | next: reserved, not yet handed to a wave
 #ifndef ADYPT_MEASURE_FP16_NODES
 constexpr int kNodeUint4 = 5;  // the 80-byte WideBVHNode, verbatim (src/BVH/WideBVH.hpp:13-26)
 #endif
@@ -56,7 +59,8 @@ constexpr int kNodeUint4 = 5;  // the 80-byte WideBVHNode, verbatim (src/BVH/Wid
 // `seg_len_lanes` holds count[s]) and a segment found exhausted is remembered in `seg_done`, so the three dependent
 // global round trips of the first version (count, cursor pre-check, atomic) shrink to one — measured: reservations
 // were 18 % of the kernel's time at 128 rays per reservation.
-__device__ __forceinline__ uint32_t fetch_rays(uint32_t seg_len_lanes, uint32_t &seg_done, uint32_t *cursor, uint32_t seg_cap, int home, uint32_t want, uint32_t *begin)
+__device__ __forceinline__ uint32_t fetch_rays(uint32_t seg_len_lanes, uint32_t &seg_done, uint32_t *cursor, uint32_t seg_cap, int home, uint32_t want, uint32_t *begin,
+                                               uint32_t *left)
 {
 	for(int k = 0; k < kNumSegments; ++k)
 	{
@@ -69,10 +73,13 @@ __device__ __forceinline__ uint32_t fetch_rays(uint32_t seg_len_lanes, uint32_t 
 		if(rel < seg_len)
 		{
 			*begin = (uint32_t)s * seg_cap + rel;
-			return min(want, seg_len - rel);
+			const uint32_t got = min(want, seg_len - rel);
+			*left = seg_len - rel - got; // rays of this segment nobody had reserved yet
+			return got;
 		}
 		seg_done |= 1u << s;
 	}
+	*left = 0;
 	return 0;
 }
 
@@ -81,10 +88,20 @@ __device__ __forceinline__ uint32_t fetch_rays(uint32_t seg_len_lanes, uint32_t 
 template <bool STATS, bool ANY = false>
 __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_trace(TraceArgs a) // hot variant: <= 96 VGPRs
 {
-	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64]
+	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64], then the workgroup's ray pool (WgPool)
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
 	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
+	// Workgroup ray pool, for the END of a launch.  A reservation from the global queue is a.chunk rays for one device atomic, and while
+	// the queue is long the wave that makes it keeps all of them (the pool stays empty: round 2's behaviour).  What a launch loses at
+	// its end is mostly the spread of the moments at which the waves next need rays (tools/wave_timeline.py: 110 us at 128 rays per
+	// wave — a wave that reserved just before the cursors ran out works on while 5119 others are done).  So once a reservation leaves
+	// fewer rays in its segment than one more chunk for every wave, the chunk goes into the pool and the 4 waves take it a.bite rays
+	// at a time (LDS compare-and-swap): the rays a wave can be left holding shrink 4x at the same number of device atomics.
+	WgPool *pool = (WgPool *)(lds_stack + (size_t)(kTraceThreads / 64) * a.lds_depth * 64);
+	if(threadIdx.x == 0) { pool->range = 0ull; pool->lock = 0u; pool->dry = 0u; }
+	__syncthreads();
+	const uint32_t endgame_rays = a.endgame * a.chunk * max(1u, (gridDim.x * (kTraceThreads / 64)) / kNumSegments); // a.endgame more chunks for every wave of the segment
 	const uint32_t total_lanes = gridDim.x * blockDim.x;
 	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
 	const int home = blockIdx.x & (kNumSegments - 1);
@@ -141,11 +158,58 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 		{
 			if(loc_next == loc_end)
 			{
-				uint32_t cb = 0;
-				const uint32_t cn = fetch_rays(seg_len_lanes, seg_done, a.cursor, a.seg_cap, home, a.chunk, &cb);
+				// a bite from the workgroup's pool (lane 0 does the LDS work, the wave shares the result)
+				uint32_t cb = 0, cn = 0, dry = 0;
+				if(lane == 0)
+				{
+					unsigned long long r = __hip_atomic_load(&pool->range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					for(;;)
+					{
+						const uint32_t nx_ = (uint32_t)r, en_ = (uint32_t)(r >> 32);
+						if(nx_ >= en_) break;
+						const uint32_t take_ = min(a.bite, en_ - nx_);
+						const unsigned long long want_ = ((unsigned long long)en_ << 32) | (nx_ + take_);
+						if(__hip_atomic_compare_exchange_strong(&pool->range, &r, want_, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { cb = nx_; cn = take_; break; }
+					}
+					if(cn == 0) dry = __hip_atomic_load(&pool->dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+				cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)cb); cn = (uint32_t)__builtin_amdgcn_readfirstlane((int)cn);
+				dry = (uint32_t)__builtin_amdgcn_readfirstlane((int)dry);
+				if(cn == 0 && !dry)
+				{
+					// the pool is empty: the wave that gets the lock reserves the next chunk for the workgroup (and takes its own bite at once);
+					// the others carry on with the rays they have and look again next trip
+					uint32_t mine = 0;
+					if(lane == 0)
+					{
+						mine = atomicCAS(&pool->lock, 0u, 1u) == 0u ? 1u : 0u;
+						if(mine)
+						{	// another wave may have refilled the pool between our look at it and our getting the lock: never overwrite rays
+							const unsigned long long r = __hip_atomic_load(&pool->range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							if((uint32_t)r < (uint32_t)(r >> 32) || __hip_atomic_load(&pool->dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+							{
+								__hip_atomic_store(&pool->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+								mine = 0; // look again next trip
+							}
+						}
+					}
+					if(__builtin_amdgcn_readfirstlane((int)mine))
+					{
+						uint32_t gb = 0, left = 0;
+						const uint32_t gn = fetch_rays(seg_len_lanes, seg_done, a.cursor, a.seg_cap, home, a.chunk, &gb, &left);
+						cb = gb; cn = left < endgame_rays ? min(a.bite, gn) : gn;
+						if(lane == 0)
+						{
+							if(gn == 0) __hip_atomic_store(&pool->dry, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							else __hip_atomic_store(&pool->range, ((unsigned long long)(gb + gn) << 32) | (gb + cn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							__hip_atomic_store(&pool->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+						}
+						dry = gn == 0 ? 1u : 0u;
+					}
+				}
 				loc_next = cb; loc_end = cb + cn;
-				if(cn == 0) { exhausted = true; ADYPT_MEASURE_WAVE_QUEUE_DRY(); }
-				else { ADYPT_MEASURE_WAVE_FIRST_RAYS(); }
+				if(cn == 0 && dry) { exhausted = true; ADYPT_MEASURE_WAVE_QUEUE_DRY(); }
+				else if(cn) { ADYPT_MEASURE_WAVE_FIRST_RAYS(); }
 			}
 			const uint32_t begin = loc_next;
 			const uint32_t got = min(n_idle, loc_end - loc_next);
