@@ -36,6 +36,8 @@ while left > 0:
     left -= m
 timed = dur[n_warm:n_warm + n_timed]
 out = {"k_trace<false,false>_launches_in_process": len(dur), "warmup_launches": n_warm, "timed_launches": len(timed),
+       # the launches a --pmc pass of the same command sees when the extra sections are switched off: warm-up + timed
+       "warmup_plus_timed_launches": n_warm + n_timed, "warmup_plus_timed_total_ms": sum(dur[:n_warm + n_timed]),
        "timed_avg_launch_ms": sum(timed) / max(1, len(timed)), "timed_launch_ms": [round(x, 4) for x in timed],
        "bench_roofline_avg_launch_ms": bench["roofline"]["avg_launch_ms"], "bench_roofline_launches": bench["roofline"]["launches"]}
 hb = bench.get("roofline_hbm_resident")

@@ -64,9 +64,10 @@ out = {
     "note": "fabric-side bytes (Infinity-Cache hits are counted, MI355X_MICROARCH.md)",
 }
 if phases:
-    key = "timed_avg_launch_ms"
-    if key in phases:
-        out["avg_launch_ms_kernel_trace"] = phases[key]
-        # the timed launches are the last ones of the process; the counters average over warm-up + timed launches of the same sizes
-        out["effective_clock_GHz"] = out["cycles_per_launch"] / (phases[key] * 1e-3) / 1e9
+    if "timed_avg_launch_ms" in phases:
+        out["avg_launch_ms_kernel_trace"] = phases["timed_avg_launch_ms"]
+    if phases.get("warmup_plus_timed_launches") == len(gui) and phases.get("warmup_plus_timed_total_ms"):
+        # the same launches in both runs (warm-up + timed frames): cycles of all of them / duration of all of them
+        out["kernel_trace_total_ms_same_launches"] = phases["warmup_plus_timed_total_ms"]
+        out["effective_clock_GHz"] = (sum(gui) / N_XCD) / (phases["warmup_plus_timed_total_ms"] * 1e-3) / 1e9
 print(json.dumps(out, indent=1))
