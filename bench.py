@@ -17,8 +17,8 @@ What the JSON line carries besides the contract's fields:
   roofline               the traversal kernel on the bench scene.  Its BVH (19 MB) is cache resident, so the HBM roof does not
                          bind; the kernel is bound by vector-ALU issue (with the CU's vector-memory pipeline close behind) ->
                          bound "valu_issue", achieved = vector-ALU issue cycles demanded per second (PMC instructions per ray x
-                         measured rays/s of the kernel x the average issue cycles of its instruction mix) against 1024 SIMDs x
-                         2.4 GHz; lane_util = fraction of the 64 lanes doing work in an issued instruction.  The algorithmic
+                         measured rays/s of the kernel x the average architectural issue cycles of its instruction mix) against
+                         1024 SIMDs x the clock the chip ran the kernel at (PMC); lane_util = fraction of the 64 lanes doing work in an issued instruction.  The algorithmic
                          HBM-read figure of SURVEY.md §8(d) and the measured fabric traffic are reported next to it.
   roofline_hbm_resident  the same kernel on the ~10 M-triangle stand-in of BASELINE config 4 (BVH 0.6 GB > 256 MB Infinity
                          Cache): here HBM binds -> bound "hbm", algorithmic bytes / HIP-event time / 8 TB/s.
@@ -69,30 +69,34 @@ def counter_figures(name):
 
 
 def valu_roofline(pmc, model, kernel_rays_s):
-    """The vector-ALU issue roof of the traversal kernel.  Everything is a formula over the committed profile and ONE live number:
-      peak      = 1024 SIMDs x effective clock, effective clock = GRBM_GUI_ACTIVE / 8 XCDs / launch duration (kernel trace of the same command)
-      achieved  = SIMD cycles with a vector-ALU instruction executing, per second = SQ_ACTIVE_INST_VALU x 4 per ray (profile) x rays/s (live)
-      frac      = achieved / peak  (>= 1 when the 4-cycle quanta of the counter over-count: read it as 'saturated')
-    and, next to it, the microbenchmark model: instructions per ray (SQ_INSTS_VALU) x rays/s x the average time an instruction of this
-    kernel's mix holds the SIMD, with the rounded (2 / 4 / 4 / 8 'cycles') and with the measured class rates — times at the
-    microbenchmark's nominal 2.4 GHz, NOT cycles at the effective clock."""
+    """The vector-ALU issue roof of the traversal kernel.  Everything is a formula over the committed profiles and ONE live number:
+      peak      = 1024 SIMDs x effective clock; effective clock = GRBM_GUI_ACTIVE / 8 XCDs / launch duration (kernel trace of the same command)
+      achieved  = issue cycles the kernel's vector-ALU instructions need per second = SQ_INSTS_VALU per ray (profile) x rays/s (live) x the
+                  average ARCHITECTURAL issue time of its instruction mix (2 cycles full-rate fp32 / logic / moves, 4 the other classes and
+                  packed fp32, 8 transcendental: profiles/r3_valu_issue_model.json)
+      frac      = achieved / peak: a fraction of a roof no instruction stream can exceed.
+    Beside it: the same with the issue times measured on one-instruction loops (profiles/r3_valu_calibration.json, true cycles: 2.46 / 4.37 /
+    4.33 / 8.24).  That figure exceeds 1 — the kernel's mixed stream issues faster than the weighted sum of single-class loops — so the loops
+    are not a roof; it is printed because VERDICT r2 asked for both.  SQ_ACTIVE_INST_VALU is NOT used: the calibration shows it counts 1 per
+    instruction (2 per transcendental) whatever the instruction's issue time."""
     clock = pmc.get("effective_clock_GHz")
     peak = N_SIMD * (clock or NOMINAL_CLOCK_GHZ)
-    busy_cycles_per_ray = pmc["SQ_ACTIVE_INST_VALU_per_launch"] * 4.0 * pmc["launches"] / pmc["rays"]
-    achieved = busy_cycles_per_ray * kernel_rays_s / 1e9
-    out = {"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "Gcycle/s", "frac": round(achieved / peak, 4),
+    inst_rate = pmc["valu_insts_per_ray"] * kernel_rays_s
+    arch = model["avg_issue_cycles_per_inst_architectural"] if model else 4.0
+    achieved = inst_rate * arch / 1e9
+    frac = achieved / peak
+    out = {"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "Gcycle/s", "frac": round(frac, 4),
            "effective_clock_GHz": round(clock, 3) if clock else None, "lane_util": round(pmc["lane_util"], 4),
-           "useful_frac": round(min(1.0, achieved / peak) * pmc["lane_util"], 4),
-           "valu_busy_frac_in_profile": round(pmc["valu_busy_frac"], 4), "valu_insts_per_ray": round(pmc["valu_insts_per_ray"], 2),
-           "valu_Ginst_s": round(pmc["valu_insts_per_ray"] * kernel_rays_s / 1e9, 1), "pmc_stale": False, "pmc_source_hash": pmc["source_hash"]}
+           "useful_frac": round(min(1.0, frac) * pmc["lane_util"], 4),
+           "valu_insts_per_ray": round(pmc["valu_insts_per_ray"], 2), "valu_Ginst_s": round(inst_rate / 1e9, 1),
+           "issue_cycles_per_inst_architectural": arch, "issue_cycles_available_per_inst": round(peak * 1e9 / inst_rate, 3),
+           "pmc_stale": False, "pmc_source_hash": pmc["source_hash"]}
     if model:
-        inst_rate = pmc["valu_insts_per_ray"] * kernel_rays_s
-        for tag in ("rounded", "measured"):
-            c = model["avg_issue_cycles_per_inst_" + tag]
-            out["model_avg_issue_cycles_per_inst_" + tag] = c
-            out["model_frac_" + tag + "_rates"] = round(inst_rate * c / (N_SIMD * model["nominal_clock_GHz_of_the_microbench_figures"] * 1e9), 4)
+        loops = model["avg_issue_cycles_per_inst_single_class_loops"]
+        out["issue_cycles_per_inst_single_class_loops"] = loops
+        out["frac_at_single_class_loop_rates"] = round(inst_rate * loops / 1e9 / peak, 4)
         if "vmem_rd_insts_per_ray" in pmc:  # the co-limiter: the CU's one vector-memory pipeline (profiles/r2_ablations_k_trace.txt)
-            out["vmem_busy_est"] = round(pmc["vmem_rd_insts_per_ray"] * kernel_rays_s * model["vmem_cycles_per_load_inst"] / (256 * model["nominal_clock_GHz_of_the_microbench_figures"] * 1e9), 3)
+            out["vmem_busy_est"] = round(pmc["vmem_rd_insts_per_ray"] * kernel_rays_s * model["vmem_cycles_per_load_inst"] / (256 * (clock or NOMINAL_CLOCK_GHZ) * 1e9), 3)
     return out
 
 
@@ -384,10 +388,10 @@ def main() -> None:
         roofline["note"] = ("BVH (nodes + Woop + index) %.0f MB is L2 / Infinity-Cache resident: alg_frac_of_hbm_peak may exceed 1 and is not a fraction of HBM "
                             "traffic (traffic = what the counters saw on the fabric).  What binds is vector-ALU issue, the CU's vector-memory pipeline close behind "
                             "(vmem_busy_est; profiles/r2_ablations_k_trace.txt).  peak = 1024 SIMDs x effective_clock_GHz (GRBM_GUI_ACTIVE / 8 / launch duration of "
-                            "the kernel trace); achieved = SQ_ACTIVE_INST_VALU x 4 cycles per ray (%s) x trace_kernel_Mrays_s of this run; frac >= 1 = saturated "
-                            "(the counter's quanta are 4 cycles).  model_frac_* = SQ_INSTS_VALU per ray x rays/s x the mix's average issue time (profiles/%s: "
-                            "rounded 2/4/4/8 and measured class rates, at the microbenchmark's nominal 2.4 GHz) / 1024 SIMDs.  lane_util = SQ_THREAD_CYCLES_VALU / "
-                            "(64 x SQ_INSTS_VALU)%s"
+                            "the kernel trace); achieved = SQ_INSTS_VALU per ray (%s) x trace_kernel_Mrays_s of this run x issue_cycles_per_inst_architectural "
+                            "(the mix's 2 / 4 / 4 / 8-cycle classes, profiles/%s); frac_at_single_class_loop_rates = the same with the class times measured on "
+                            "one-instruction loops (profiles/r3_valu_calibration.json), > 1 because a mixed stream issues faster than those loops: not a roof.  "
+                            "lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)%s"
                             % (bvh_mb, pmc.get("command", "?"), ISSUE_MODEL, "; per-ray figures of the 1-GPU passes applied to rank 0's shard" if world > 1 else ""))
     else:
         roofline.update({"bound": "hbm (algorithmic bytes; the scene is cache resident)", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

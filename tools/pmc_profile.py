@@ -57,7 +57,8 @@ out = {
     "SQ_ACTIVE_INST_VALU_per_launch": sum(active_valu) / max(1, len(active_valu)),
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = the launch's duration in shader-clock cycles
     "cycles_per_launch": sum(gui) / max(1, len(gui)) / N_XCD,
-    # fraction of all SIMD cycles of the launch in which a vector-ALU instruction was executing: SQ_ACTIVE_INST_VALU counts in units of 4 cycles
+    # NOT a busy fraction: profiles/r3_valu_calibration.json shows SQ_ACTIVE_INST_VALU = 1 per instruction (2 per transcendental) whatever
+    # its issue time, so x 4 over-counts full-rate instructions (kept for comparison with rounds 1-2, unused by bench.py)
     "valu_busy_frac": (sum(active_valu) * 4.0) / max(1.0, N_SIMD * sum(gui) / N_XCD),
     "cycles_per_valu_inst_per_simd": (N_SIMD * sum(gui) / N_XCD) / max(1.0, sum(insts)),
     "source_hash": device_source_hash(),
