@@ -94,17 +94,17 @@ __device__ inline void canon_sincos(float xf, float *s_out, float *c_out)
 	*c_out = (float)c;
 }
 
-// c / 255 for an 8-bit c (RG8 / RGB8 UNORM decoding): the correctly rounded binary32 quotients, folded at compile time.
-// A table load instead of the ~10-instruction IEEE division sequence — k_shade decodes 2 shift bytes per path and 12
-// texel channels per textured hit, and it is VALU-bound (profiles/: 74 % VALU busy).
-#define ADYPT_U8(i) ((float)(i) / 255.0f)
-#define ADYPT_U8x8(b) ADYPT_U8(b), ADYPT_U8(b + 1), ADYPT_U8(b + 2), ADYPT_U8(b + 3), ADYPT_U8(b + 4), ADYPT_U8(b + 5), ADYPT_U8(b + 6), ADYPT_U8(b + 7)
-#define ADYPT_U8x64(b) ADYPT_U8x8(b), ADYPT_U8x8(b + 8), ADYPT_U8x8(b + 16), ADYPT_U8x8(b + 24), ADYPT_U8x8(b + 32), ADYPT_U8x8(b + 40), ADYPT_U8x8(b + 48), ADYPT_U8x8(b + 56)
-__device__ const float kUnorm8[256] = {ADYPT_U8x64(0), ADYPT_U8x64(64), ADYPT_U8x64(128), ADYPT_U8x64(192)};
-#undef ADYPT_U8x64
-#undef ADYPT_U8x8
-#undef ADYPT_U8
-__device__ __forceinline__ float unorm8_to_float(uint32_t c) { return kUnorm8[c & 0xffu]; }
+// c / 255 for an 8-bit c (RG8 / RGB8 UNORM decoding): the correctly rounded binary32 quotient without the ~10-instruction IEEE
+// division sequence and without a table.  q = c * rn(1/255) is off by at most one ulp; the remainder c - 255 q is exact in an fma,
+// and one correction step lands on rn(c / 255) for every c in 0..255 (checked with exact rational arithmetic over all 256 inputs,
+// tests/test_oracle_golden.py::test_unorm8_decode_formula; the oracle divides).  Round 3: the 256-entry table this replaces cost a
+// dependent vector-memory instruction per channel — 14 per textured path — on the pipeline k_shade is bound by.
+__device__ __forceinline__ float unorm8_to_float(uint32_t c)
+{
+	const float x = (float)(c & 0xffu), r = 0x1.010102p-8f; // rn(1 / 255)
+	const float q = x * r;
+	return fmaf(fmaf(-q, 255.0f, x), r, q);
+}
 
 __device__ inline float canon_pow(float xf, float yf)
 {

@@ -94,7 +94,19 @@ struct SceneArgs {
 	const uint32_t *texels;        // RGBA8, all textures back to back
 	const int4 *tex_desc;          // (offset, w, h, 0) per texture
 	const int32_t *local_blocks;   // global block id of each owned block
+	const uint8_t *tri_class;      // per triangle: shading class of its material, 1..6 (material_class); null = k_shade does not bin
 };
+
+// Shading class of a material = which code of Render() a path that hits it runs (pathtracer.glsl:144-201) — only a SORT KEY for
+// k_shade's in-workgroup binning, never an input of the arithmetic.  0 is the key of a miss, 7 of a thread without a path.
+constexpr uint32_t kClassMiss = 0, kClassNone = 7;
+inline uint32_t material_class(int illum, float shininess, bool textured)
+{
+	if(illum == 2 && shininess * 0.01f > 0.3f) return textured ? 4u : 3u; // glossy lobe: two canon_pow + sincos
+	if(illum == 1 || illum == 2) return textured ? 2u : 1u;                // diffuse lobe
+	if(illum == 6 || illum == 7) return 6u;                                // dielectric
+	return 5u;                                                             // mirror (3..5) and pass-through (0, 8+)
+}
 
 struct QueueArgs {
 	float *ray_o; float4 *ray_d; float *col; // queue being read (shade) / written (gen): 3 floats, float4, 3 floats per slot
@@ -204,6 +216,38 @@ __device__ __forceinline__ uint32_t append_slot(bool alive, uint32_t *seg_counte
 	return seg_base + wave_base[wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// In-workgroup counting sort of the workgroup's 256 paths by an 8-valued key: returns the index (0..255) of the thread whose path
+// THIS thread takes over, such that keys ascend with threadIdx.x — waves then run one class of material code instead of all of them
+// under exec masks.  Stable (ties keep thread order).  Per wave 8 votes; the 32 (class, wave) counts meet in LDS.
+__device__ __forceinline__ uint32_t bin_by_key(uint32_t key)
+{
+	__shared__ uint32_t count[8][kShadeThreads / 64];
+	__shared__ uint16_t source[kShadeThreads];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t rank = 0;
+#pragma unroll
+	for(uint32_t c = 0; c < 8; ++c)
+	{
+		const unsigned long long mask = __ballot(key == c);
+		if(lane == 0) count[c][wave] = (uint32_t)__popcll(mask);
+		if(key == c) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+	}
+	__syncthreads();
+	uint32_t before = 0, base = 0; // paths of lower classes; + paths of this class in lower waves
+#pragma unroll
+	for(uint32_t c = 0; c < 8; ++c)
+	{
+		uint32_t lower_waves = 0, all = 0;
+#pragma unroll
+		for(int w = 0; w < kShadeThreads / 64; ++w) { const uint32_t n = count[c][w]; if(w < wave) lower_waves += n; all += n; }
+		if(key == c) base = before + lower_waves;
+		before += all;
+	}
+	source[base + rank] = (uint16_t)threadIdx.x;
+	__syncthreads();
+	return source[threadIdx.x];
+}
+
 // use_cache: the frame reuses the cached primary hit (spp % tmpLife != 0, pathtracer.glsl:115-120) — the hit
 // record is copied next to the ray and the host skips the bounce-0 traversal launch.
 // bias_mode 0: Camera() of primaryray.glsl (no sub-pixel bias); 1: Camera(SubPixel()) of pathtracer.glsl
@@ -294,6 +338,15 @@ __device__ inline F3 sample_texture(const SceneArgs &sc, int tex, float s, float
 	return r;
 }
 
+// Measurement hook, identity in the product.  -DADYPT_MEASUREMENT_BUILD -DADYPT_ABLATE_SHADE_TRI_L2 folds k_shade's triangle gather onto
+// the first 16384 records (2 MB: resident in every XCD's L2) — wrong images, but the kernel's time then says what the gathers' misses cost
+// (profiles/r3_ablations_k_trace.txt item 10).
+#if defined(ADYPT_MEASUREMENT_BUILD) && defined(ADYPT_ABLATE_SHADE_TRI_L2)
+#define ADYPT_MEASURE_SHADE_GATHER_INDEX(i) ((i) & 16383)
+#else
+#define ADYPT_MEASURE_SHADE_GATHER_INDEX(i) (i)
+#endif
+
 // the always-needed 80 bytes of a triangle: positions, normals, material id
 struct TriCore { float v[20]; };
 __device__ __forceinline__ TriCore load_tri_core(const SceneArgs &sc, int tri_idx)
@@ -367,7 +420,18 @@ __global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneAr
 	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
 	const uint32_t n_in = q.count_in[seg * kCursorStride];
 	if(chunk * kShadeThreads >= n_in) return; // whole workgroup beyond the segment's live range (uniform exit)
-	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
+	uint32_t local = chunk * kShadeThreads + threadIdx.x;
+	if(sc.tri_class) // (kernel argument: uniform branch around the barriers of bin_by_key)
+	{
+		// the workgroup's paths change hands so that every wave shades one class of material: the hit's triangle names the class
+		uint32_t key = kClassNone;
+		if(local < n_in)
+		{
+			const int tri = __float_as_int(q.hit[3 * ((size_t)seg * q.seg_cap + local)]);
+			key = tri < 0 || tri >= f.n_tris ? kClassMiss : (uint32_t)sc.tri_class[tri];
+		}
+		local = chunk * kShadeThreads + bin_by_key(key);
+	}
 	const uint32_t slot_in = seg * q.seg_cap + local;
 	bool alive = local < n_in;
 	F3 origin = f3(0, 0, 0), dir = f3(0, 0, 1), color = f3(0, 0, 0), ret = f3(0, 0, 0);
@@ -406,9 +470,14 @@ __global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneAr
 		}
 		else
 		{
-			const TriCore tc = load_tri_core(sc, tri_idx);
+			const TriCore tc = load_tri_core(sc, ADYPT_MEASURE_SHADE_GATHER_INDEX(tri_idx));
 			const float *tri = tc.v;
 			const int matid = __float_as_int(tri[18]);
+			// the hit's geometry before the material is looked at: all five loads of the record are then in flight together (with the
+			// interpolation under the material test the compiler fetched the material id first and the rest one round trip later)
+			const float w = 1.0f - tu - tv;
+			F3 normal = normalize3(bary3(tri + 9, tri + 12, tri + 15, tu, tv, w));
+			origin = bary3(tri + 0, tri + 3, tri + 6, tu, tv, w);
 			if(matid < 0 || matid >= f.n_mats) { alive = false; bad_mat = true; }
 			else
 			{
@@ -417,9 +486,6 @@ __global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneAr
 				const float4 md = mp[0], me = mp[1], ms = mp[2], mx = mp[3];
 				const int dtex = __float_as_int(md.x), illum0 = __float_as_int(mx.x);
 				const float shininess = mx.y, ior = mx.w;
-				const float w = 1.0f - tu - tv;
-				F3 normal = normalize3(bary3(tri + 9, tri + 12, tri + 15, tu, tv, w));
-				origin = bary3(tri + 0, tri + 3, tri + 6, tu, tv, w);
 				F3 diffuse;
 				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) diffuse = textured_diffuse(sc, tri_idx, dtex, tu, tv, w);
 				else diffuse = f3(md.y, md.z, md.w);

@@ -67,7 +67,7 @@ struct adypt_ctx {
 	std::string error;
 
 	// scene (immutable after create)
-	void *d_nodes = nullptr, *d_woop = nullptr, *d_tri_indices = nullptr, *d_triangles = nullptr, *d_materials = nullptr;
+	void *d_nodes = nullptr, *d_woop = nullptr, *d_tri_indices = nullptr, *d_triangles = nullptr, *d_materials = nullptr, *d_tri_class = nullptr;
 	void *d_texels = nullptr, *d_tex_desc = nullptr, *d_local_blocks = nullptr;
 	void *d_all_blocks = nullptr;             // adypt_assemble_radiance: block lists of all ranks
 	std::vector<int64_t> all_blocks_offset;
@@ -355,6 +355,7 @@ void fill_scene(const adypt_ctx *c, SceneArgs *s)
 	s->texels = (const uint32_t *)c->d_texels;
 	s->tex_desc = (const int4 *)c->d_tex_desc;
 	s->local_blocks = (const int32_t *)c->d_local_blocks;
+	s->tri_class = (const uint8_t *)c->d_tri_class;
 }
 void fill_pixels(const adypt_ctx *c, PixelArgs *p)
 {
@@ -672,6 +673,25 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	}
 	TRY_CREATE(upload(c, &c->d_materials, (const uint8_t *)d->materials, (size_t)d->n_mats * 64));
 	{
+		// k_shade's sort key per triangle (shade.hpp: material_class).  Off unless ADYPT_SHADE_BIN=1: measured +10 % k_shade time on both
+		// bench scenes (profiles/r3_ablations_k_trace.txt item 9) — the kernel waits on its gathers, not on divergent vector-ALU work
+		const char *ov = getenv("ADYPT_SHADE_BIN");
+		if(ov && atoi(ov) != 0)
+		{
+			std::vector<uint8_t> cls((size_t)std::max<int64_t>(d->n_tris, 1), (uint8_t)5);
+			const uint8_t *tri = (const uint8_t *)d->triangles, *mat = (const uint8_t *)d->materials;
+			for(int64_t i = 0; i < d->n_tris; ++i)
+			{
+				int32_t matid, dtex, illum; float shininess;
+				memcpy(&matid, tri + i * 100 + 96, 4);
+				if(matid < 0 || matid >= d->n_mats) continue;
+				memcpy(&dtex, mat + (size_t)matid * 64, 4); memcpy(&illum, mat + (size_t)matid * 64 + 48, 4); memcpy(&shininess, mat + (size_t)matid * 64 + 52, 4);
+				cls[(size_t)i] = (uint8_t)material_class(illum, shininess, d->n_textures != 0 && dtex >= 0 && dtex < d->n_textures);
+			}
+			TRY_CREATE(upload(c, &c->d_tri_class, cls.data(), cls.size()));
+		}
+	}
+	{
 		std::vector<uint32_t> texels;
 		std::vector<int32_t> desc;
 		for(int t = 0; t < d->n_textures; ++t)
@@ -738,7 +758,7 @@ void adypt_destroy(adypt_ctx *c)
 	c->comm = nullptr;
 	for(EventPair &p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_texels, c->d_tex_desc, c->d_local_blocks,
+	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_tri_class, c->d_texels, c->d_tex_desc, c->d_local_blocks,
 					c->d_accum, c->d_cache, c->d_cache_next, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
 					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol, c->d_display};
 	for(void *b : bufs) if(b) (void)hipFree(b);

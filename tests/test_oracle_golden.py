@@ -194,3 +194,22 @@ def test_sun_visibility_option_of_the_oracle(sobol_matrices):
     assert np.array_equal(imgs[False].view(np.uint32), ref.view(np.uint32))
     assert rays[True] > rays[False] and (imgs[True][..., :3] <= imgs[False][..., :3]).all()
     assert (imgs[True][..., :3] < imgs[False][..., :3]).any()
+
+
+def test_unorm8_decode_formula():
+    """The device decodes c / 255 as q = c * rn(1/255); q + rn(c - 255 q) * rn(1/255) with fused steps (csrc/device/canon_math.hpp:
+    unorm8_to_float) where the oracle divides.  Exact rational arithmetic, every rounding to the nearest binary32: identical for all 256 c."""
+    from fractions import Fraction
+
+    def rn32(fr):
+        f = np.float32(float(fr))
+        cands = [f, np.nextafter(f, np.float32(np.inf)), np.nextafter(f, np.float32(-np.inf))]
+        return np.float32(min(cands, key=lambda x: (abs(Fraction(float(x)) - fr), int(np.float32(x).view(np.uint32)) & 1)))
+
+    r = Fraction(float.fromhex("0x1.010102p-8"))
+    assert rn32(Fraction(1, 255)) == np.float32(float(r))
+    for c in range(256):
+        q = Fraction(float(rn32(c * r)))
+        e = Fraction(float(rn32(c - 255 * q)))       # fmaf(-q, 255, c)
+        got = rn32(q + e * r)                           # fmaf(e, r, q)
+        assert got == np.float32(c) / np.float32(255.0), c
