@@ -37,6 +37,7 @@ constexpr int kNumSegments = 8;                // one ray-queue segment per XCD
 constexpr int kCursorStride = 32;              // uint32 words between per-segment counters: one 128-byte line each
 constexpr int kShadeThreads = 256;             // workgroup of the gen / shade / viewer kernels = one queue chunk
 constexpr int kTriFloat4 = 8;                  // device triangle record: 8 x float4 = one 128-byte line
+constexpr int kMatFloat4 = 5;                  // device material record: the reference's 64 bytes + (texel offset, w, h, 0) of its diffuse texture
 constexpr uint32_t kPathParked = 0x80000000u;  // path word: the path's radiance so far is parked in FrameArgs::done[path id]
 constexpr uint32_t kPathIdMask = 0x7fffffffu;
 
@@ -90,9 +91,8 @@ struct FrameArgs {
 
 struct SceneArgs {
 	const float4 *triangles;       // kTriFloat4 float4 per triangle (repacked, see header)
-	const float4 *materials;       // 4 x float4 per material
-	const uint32_t *texels;        // RGBA8, all textures back to back
-	const int4 *tex_desc;          // (offset, w, h, 0) per texture
+	const float4 *materials;       // kMatFloat4 x float4 per material
+	const uint32_t *texels;        // RGBA8, all textures back to back; every row is followed by a copy of its first texel (w + 1 per row)
 	const int32_t *local_blocks;   // global block id of each owned block
 	const uint8_t *tri_class;      // per triangle: shading class of its material, 1..6 (material_class); null = k_shade does not bin
 };
@@ -314,10 +314,12 @@ __global__ __launch_bounds__(256) void k_resolve(FrameArgs f, SceneArgs sc, Pixe
 
 __device__ __forceinline__ int pos_mod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
 
-// GL_LINEAR / GL_REPEAT / RGB8, single level, canonical fp32 weights (see oracle.cpp sample_texture)
-__device__ inline F3 sample_texture(const SceneArgs &sc, int tex, float s, float t)
+// GL_LINEAR / GL_REPEAT / RGB8, single level, canonical fp32 weights (see oracle.cpp sample_texture).  d = (texel offset, w, h) from the
+// material record.  The two texels of a row come in one 8-byte load: rows are stored w + 1 texels long, the last one a copy of the
+// first, so (i0, i0 + 1) is the wrapped pair too — 2 vector-memory instructions per sample instead of 4.
+struct __attribute__((packed, aligned(4))) TexelPair { uint32_t a, b; };
+__device__ inline F3 sample_texture(const SceneArgs &sc, int4 d, float s, float t)
 {
-	const int4 d = sc.tex_desc[tex];
 	const int w = d.y, h = d.z;
 	const uint32_t *tx = sc.texels + d.x;
 	const float uu = fmaf(s, (float)w, -0.5f), vv = fmaf(t, (float)h, -0.5f);
@@ -325,16 +327,14 @@ __device__ inline F3 sample_texture(const SceneArgs &sc, int tex, float s, float
 	const float a = uu - fu, b = vv - fv;
 	fu = gl_min(gl_max(fu, -1e9f), 1e9f); fv = gl_min(gl_max(fv, -1e9f), 1e9f);
 	const int i0 = pos_mod((int)fu, w), j0 = pos_mod((int)fv, h);
-	const int i1 = i0 + 1 == w ? 0 : i0 + 1, j1 = j0 + 1 == h ? 0 : j0 + 1;
-	auto texel = [&](int i, int j) {
-		const uint32_t p = tx[(size_t)j * w + i];
-		return f3(unorm8_to_float(p), unorm8_to_float(p >> 8), unorm8_to_float(p >> 16));
-	};
+	const int j1 = j0 + 1 == h ? 0 : j0 + 1;
+	const TexelPair r0 = *(const TexelPair *)(tx + (size_t)j0 * (size_t)(w + 1) + i0), r1 = *(const TexelPair *)(tx + (size_t)j1 * (size_t)(w + 1) + i0);
+	auto rgb = [](uint32_t p) { return f3(unorm8_to_float(p), unorm8_to_float(p >> 8), unorm8_to_float(p >> 16)); };
 	const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-	F3 r = texel(i0, j0) * w00;
-	r = fma3(texel(i1, j0), w10, r);
-	r = fma3(texel(i0, j1), w01, r);
-	r = fma3(texel(i1, j1), w11, r);
+	F3 r = rgb(r0.a) * w00;
+	r = fma3(rgb(r0.b), w10, r);
+	r = fma3(rgb(r1.a), w01, r);
+	r = fma3(rgb(r1.b), w11, r);
 	return r;
 }
 
@@ -366,13 +366,13 @@ __device__ __forceinline__ F3 bary3(const float *a, const float *b, const float 
 	r = fma3(f3(c[0], c[1], c[2]), w, r);
 	return r;
 }
-__device__ __forceinline__ F3 textured_diffuse(const SceneArgs &sc, int tri_idx, int dtex, float u, float v, float w)
+__device__ __forceinline__ F3 textured_diffuse(const SceneArgs &sc, int tri_idx, int4 desc, float u, float v, float w)
 {
 	const float4 *p = sc.triangles + (size_t)tri_idx * kTriFloat4 + 5;
 	const float4 a = p[0], b = p[1]; // tc0.xy tc1.xy | tc2.xy pad
 	const float ts = fmaf(b.x, w, fmaf(a.z, v, a.x * u));
 	const float tt = fmaf(b.y, w, fmaf(a.w, v, a.y * u));
-	return sample_texture(sc, dtex, ts, tt);
+	return sample_texture(sc, desc, ts, tt);
 }
 
 struct Rng { float sx, sy; const float *sobol; };
@@ -412,14 +412,11 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 	px.accum[L] = make_float4(fmaf(old.x, fs, r.x) / fs1, fmaf(old.y, fs, r.y) / fs1, fmaf(old.z, fs, r.z) / fs1, 1.0f);
 }
 
-// One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for every live path.
+// One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for the 256 live paths of queue chunk `chunk` of segment `seg`.
 // store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
-// 7 waves per SIMD (72 VGPRs): measured optimum (6: -2.4 %, 8 needs spills: +19 % kernel time; profiles/r2_ablations_k_trace.txt)
-__global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, ShadowArgs sh, int b, int store_cache, int count_stats)
+__device__ __forceinline__ void shade_chunk(const FrameArgs &f, const SceneArgs &sc, const QueueArgs &q, const PixelArgs &px, const ShadowArgs &sh, int b,
+											 int store_cache, int count_stats, uint32_t seg, uint32_t chunk, uint32_t n_in)
 {
-	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
-	const uint32_t n_in = q.count_in[seg * kCursorStride];
-	if(chunk * kShadeThreads >= n_in) return; // whole workgroup beyond the segment's live range (uniform exit)
 	uint32_t local = chunk * kShadeThreads + threadIdx.x;
 	if(sc.tri_class) // (kernel argument: uniform branch around the barriers of bin_by_key)
 	{
@@ -482,12 +479,13 @@ __global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneAr
 			else
 			{
 				shaded = true;
-				const float4 *mp = sc.materials + (size_t)matid * 4;
-				const float4 md = mp[0], me = mp[1], ms = mp[2], mx = mp[3];
+				const float4 *mp = sc.materials + (size_t)matid * kMatFloat4;
+				const float4 md = mp[0], me = mp[1], ms = mp[2], mx = mp[3], mt = mp[4];
 				const int dtex = __float_as_int(md.x), illum0 = __float_as_int(mx.x);
 				const float shininess = mx.y, ior = mx.w;
+				const int4 tex_desc = make_int4(__float_as_int(mt.x), __float_as_int(mt.y), __float_as_int(mt.z), 0);
 				F3 diffuse;
-				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) diffuse = textured_diffuse(sc, tri_idx, dtex, tu, tv, w);
+				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) diffuse = textured_diffuse(sc, tri_idx, tex_desc, tu, tv, w);
 				else diffuse = f3(md.y, md.z, md.w);
 				const F3 specular = f3(ms.y, ms.z, ms.w);
 				ret = fma3(color, f3(me.y, me.z, me.w), ret);
@@ -596,6 +594,17 @@ __global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneAr
 	}
 }
 
+// One workgroup per chunk.  Round 3 measured the alternatives (profiles/r3_ablations_k_trace.txt items 9-12): several chunks per workgroup (the
+// kernel is not bound by the dispatch rate), 8 waves per SIMD (+4 %), the material table in LDS, binning by material class (+10 %).
+// 7 waves per SIMD (72 VGPRs): measured optimum (6: -2.4 %)
+__global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, ShadowArgs sh, int b, int store_cache, int count_stats)
+{
+	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
+	const uint32_t n_in = q.count_in[seg * kCursorStride];
+	if(chunk * kShadeThreads >= n_in) return; // whole workgroup beyond the segment's live range (uniform exit)
+	shade_chunk(f, sc, q, px, sh, b, store_cache, count_stats, seg, chunk, n_in);
+}
+
 // pathtracer.glsl:130-135 with the commented-out condition enabled: the escaped path receives the sun term only if the
 // any-hit query towards the sun found nothing; then main()'s clamp + accumulate (:224-226)
 __global__ __launch_bounds__(kShadeThreads) void k_shadow_resolve(FrameArgs f, QueueArgs q, PixelArgs px, ShadowArgs sh)
@@ -637,13 +646,14 @@ __global__ __launch_bounds__(kShadeThreads) void k_viewer(FrameArgs f, SceneArgs
 		const int matid = __float_as_int(tri[18]);
 		if(matid >= 0 && matid < f.n_mats)
 		{
-			const float4 *mp = sc.materials + (size_t)matid * 4;
-			const float4 md = mp[0], me = mp[1], ms = mp[2];
+			const float4 *mp = sc.materials + (size_t)matid * kMatFloat4;
+			const float4 md = mp[0], me = mp[1], ms = mp[2], mt = mp[4];
 			const int dtex = __float_as_int(md.x);
+			const int4 tex_desc = make_int4(__float_as_int(mt.x), __float_as_int(mt.y), __float_as_int(mt.z), 0);
 			const float w = 1.0f - u - v;
 			if(viewer_type == 0)
 			{
-				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) color = textured_diffuse(sc, tri_idx, dtex, u, v, w);
+				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) color = textured_diffuse(sc, tri_idx, tex_desc, u, v, w);
 				else color = f3(md.y, md.z, md.w);
 			}
 			else if(viewer_type == 1) color = f3(ms.y, ms.z, ms.w);

@@ -68,7 +68,7 @@ struct adypt_ctx {
 
 	// scene (immutable after create)
 	void *d_nodes = nullptr, *d_woop = nullptr, *d_tri_indices = nullptr, *d_triangles = nullptr, *d_materials = nullptr, *d_tri_class = nullptr;
-	void *d_texels = nullptr, *d_tex_desc = nullptr, *d_local_blocks = nullptr;
+	void *d_texels = nullptr, *d_local_blocks = nullptr;
 	void *d_all_blocks = nullptr;             // adypt_assemble_radiance: block lists of all ranks
 	std::vector<int64_t> all_blocks_offset;
 	int64_t n_nodes = 0, n_refs = 0, n_tris = 0, n_mats = 0;
@@ -353,7 +353,6 @@ void fill_scene(const adypt_ctx *c, SceneArgs *s)
 	s->triangles = (const float4 *)c->d_triangles;
 	s->materials = (const float4 *)c->d_materials;
 	s->texels = (const uint32_t *)c->d_texels;
-	s->tex_desc = (const int4 *)c->d_tex_desc;
 	s->local_blocks = (const int32_t *)c->d_local_blocks;
 	s->tri_class = (const uint8_t *)c->d_tri_class;
 }
@@ -671,7 +670,6 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		}
 		TRY_CREATE(upload(c, &c->d_triangles, packed.data(), packed.size()));
 	}
-	TRY_CREATE(upload(c, &c->d_materials, (const uint8_t *)d->materials, (size_t)d->n_mats * 64));
 	{
 		// k_shade's sort key per triangle (shade.hpp: material_class).  Off unless ADYPT_SHADE_BIN=1: measured +10 % k_shade time on both
 		// bench scenes (profiles/r3_ablations_k_trace.txt item 9) — the kernel waits on its gathers, not on divergent vector-ALU work
@@ -692,6 +690,8 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		}
 	}
 	{
+		// textures: RGB8 -> RGBA8 words, every row w + 1 texels long — the extra one repeats the row's first texel, so the horizontal
+		// neighbour of the last column (GL_REPEAT) sits next to it and sample_texture fetches a row's two texels in one 8-byte load
 		std::vector<uint32_t> texels;
 		std::vector<int32_t> desc;
 		for(int t = 0; t < d->n_textures; ++t)
@@ -699,13 +699,28 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 			const adypt_texture &tx = d->textures[t];
 			if(tx.width <= 0 || tx.height <= 0 || !tx.rgb) { c->error = "adypt_create: bad texture " + std::to_string(t); return bail(ADYPT_E_INVALID); }
 			desc.push_back((int32_t)texels.size()); desc.push_back(tx.width); desc.push_back(tx.height); desc.push_back(0);
-			const size_t n = (size_t)tx.width * tx.height;
-			const size_t base = texels.size();
-			texels.resize(base + n);
-			for(size_t i = 0; i < n; ++i) texels[base + i] = (uint32_t)tx.rgb[i * 3] | (uint32_t)tx.rgb[i * 3 + 1] << 8 | (uint32_t)tx.rgb[i * 3 + 2] << 16 | 0xff000000u;
+			const size_t base = texels.size(), row = (size_t)tx.width + 1;
+			if(base + row * (size_t)tx.height >= ((size_t)1 << 31)) { c->error = "adypt_create: more than 2^31 texels"; return bail(ADYPT_E_INVALID); }
+			texels.resize(base + row * (size_t)tx.height);
+			for(int y = 0; y < tx.height; ++y)
+			{
+				uint32_t *o = texels.data() + base + row * (size_t)y;
+				const uint8_t *in = tx.rgb + (size_t)y * tx.width * 3;
+				for(int x = 0; x < tx.width; ++x) o[x] = (uint32_t)in[x * 3] | (uint32_t)in[x * 3 + 1] << 8 | (uint32_t)in[x * 3 + 2] << 16 | 0xff000000u;
+				o[tx.width] = o[0];
+			}
 		}
 		TRY_CREATE(upload(c, &c->d_texels, texels.data(), texels.size()));
-		TRY_CREATE(upload(c, &c->d_tex_desc, desc.data(), desc.size()));
+		// materials: the reference's 64 bytes + the descriptor of the diffuse texture (one fetch less per textured hit)
+		std::vector<uint8_t> mats((size_t)std::max<int64_t>(d->n_mats, 1) * kMatFloat4 * 16, 0);
+		for(int64_t m = 0; m < d->n_mats; ++m)
+		{
+			uint8_t *o = mats.data() + (size_t)m * kMatFloat4 * 16;
+			memcpy(o, (const uint8_t *)d->materials + (size_t)m * 64, 64);
+			int32_t dtex; memcpy(&dtex, o, 4);
+			if(dtex >= 0 && dtex < d->n_textures) memcpy(o + 64, desc.data() + (size_t)dtex * 4, 16);
+		}
+		TRY_CREATE(upload(c, &c->d_materials, mats.data(), mats.size()));
 	}
 	TRY_CREATE(upload(c, &c->d_local_blocks, c->local_blocks.data(), c->local_blocks.size()));
 
@@ -758,7 +773,7 @@ void adypt_destroy(adypt_ctx *c)
 	c->comm = nullptr;
 	for(EventPair &p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_tri_class, c->d_texels, c->d_tex_desc, c->d_local_blocks,
+	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_tri_class, c->d_texels, c->d_local_blocks,
 					c->d_accum, c->d_cache, c->d_cache_next, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
 					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol, c->d_display};
 	for(void *b : bufs) if(b) (void)hipFree(b);
