@@ -141,7 +141,7 @@ struct PixelArgs {
 // Keeps VGPRs allocated beyond the kernel's highest register (the clobber makes `reg`, the first one of the next granule of 8,
 // count as used).  Precaution
 // that goes with the append_slot note below: the misbehaving build of k_gen_primary had exactly 16 VGPRs, the same instructions with
-// 24 allocated did not misbehave.  tools/check_vgpr.py fails the build when a kernel's count lands on a multiple of 8 without it.
+// 24 allocated did not misbehave.  tools/check_vgpr.py lists every kernel's count and fails when one of these small kernels lands on a multiple of 8.
 #define ADYPT_VGPR_SLACK(reg) asm volatile("; one spare VGPR granule" ::: reg)
 
 __device__ __forceinline__ bool local_pixel_xy(const FrameArgs &f, const int32_t *local_blocks, int L, int *x, int *y)

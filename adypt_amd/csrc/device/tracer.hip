@@ -279,6 +279,11 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
 	c->occupancy_api = per_cu;
 	per_cu = std::max(1, std::min(per_cu, 8));
+	// 80 VGPRs allow 6 waves per SIMD.  Measured (round 3, tools/sweep_env.py): 6 instead of 5 workgroups per CU is +2.6 % on the bench scene
+	// (BVH 20 MB), +2 % on the 1.2 M-triangle scene (69 MB) and -1 % on the 10 M-triangle scene (602 MB), where the sixth wave's lines evict
+	// the others' from the caches: a BVH beyond the 256 MB Infinity Cache keeps 5
+	const size_t bvh_bytes = (size_t)c->n_nodes * 80 + (size_t)c->n_refs * 52;
+	if(bvh_bytes > ((size_t)256 << 20)) per_cu = std::min(per_cu, 5);
 	if(const char *ov = getenv("ADYPT_TRACE_BLOCKS_PER_CU")) // tuning override
 	{
 		const int want = std::max(1, std::min(16, atoi(ov)));

@@ -1,9 +1,10 @@
-"""Build check: lists the VGPR count of every gfx950 kernel of the library and fails when one lands exactly on an allocation-granule
-boundary (a multiple of 8) — see the append_slot note in adypt_amd/csrc/device/shade.hpp.  python tools/check_vgpr.py"""
+"""Build check: lists the VGPR count of every gfx950 kernel of the library and marks those that land exactly on an allocation-granule
+boundary (a multiple of 8).  Fails only for the small kernels that call append_slot and carry ADYPT_VGPR_SLACK for that reason (DESIGN.md
+§10); the traversal kernel is MEANT to sit on 80 (6 waves per SIMD).  python tools/check_vgpr.py"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "adypt_amd", "csrc")
-FLAGS = "-std=c++17 -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -munsafe-fp-atomics -fno-slp-vectorize -DADYPT_BUILD --cuda-device-only -S".split()
+FLAGS = "-std=c++17 -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -munsafe-fp-atomics -fno-slp-vectorize -mllvm -disable-machine-licm -DADYPT_BUILD --cuda-device-only -S".split()
 bad = []
 for src in ("device/tracer.hip", "device/multi.hip"):
     with tempfile.NamedTemporaryFile(suffix=".s") as t:
@@ -13,6 +14,6 @@ for src in ("device/tracer.hip", "device/multi.hip"):
         n = int(n)
         flag = "  <-- on a granule boundary" if n % 8 == 0 else ""
         print("%4d  %s%s" % (n, name, flag))
-        if n % 8 == 0:
+        if n % 8 == 0 and ("k_gen_primary" in name or "k_viewer" in name or "k_shadow_resolve" in name):
             bad.append(name)
 sys.exit(1 if bad else 0)
