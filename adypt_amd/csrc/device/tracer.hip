@@ -116,6 +116,7 @@ struct adypt_ctx {
 	// launch geometry of the persistent traversal kernel
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0, occupancy_api = 0;
 	uint32_t refill_min = kRefillMin, chunk = kChunk, bite = kBite, endgame = kEndgame;
+	int deal_chunks = 1;           // k_gen_primary deals 256-path chunks round-robin to the 8 queue segments (ADYPT_GEN_DEAL=0: one contiguous run each)
 
 	// state
 	adypt_pt_params params{}, pending{};
@@ -352,6 +353,7 @@ void fill_frame(const adypt_ctx *c, FrameArgs *f)
 	f->sobol = c->d_sobol; f->done = c->d_done; f->n_frames = 1; f->frame_first = 0; f->frame_stride = 1; f->batched = 0;
 	f->n_local_px = c->n_local_px; f->blocks_x = c->blocks_x; f->rank = c->rank; f->nranks = c->nranks;
 	f->n_tris = (int32_t)c->n_tris; f->n_mats = (int32_t)c->n_mats; f->n_tex = c->n_tex;
+	f->deal_chunks = c->deal_chunks;
 }
 void fill_scene(const adypt_ctx *c, SceneArgs *s)
 {
@@ -636,6 +638,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
 	c->num_cus = prop.multiProcessorCount;
 	if(const char *ov = getenv("ADYPT_REFILL_MIN")) c->refill_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
+	if(const char *ov = getenv("ADYPT_GEN_DEAL")) c->deal_chunks = atoi(ov) != 0;
 	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_ENDGAME")) c->endgame = (uint32_t)std::max(0, std::min(1024, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_BITE")) c->bite = (uint32_t)std::max(1, std::min(4096, atoi(ov)));
