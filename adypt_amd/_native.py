@@ -100,6 +100,7 @@ _SIGS = {
     "adypt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "adypt_reset_stats": (C.c_int, [C.c_void_p]),
     "adypt_get_wave_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "adypt_get_shader_clock": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "adypt_local_pixel_count": (C.c_int64, [C.c_void_p]),
     "adypt_set_sun_visibility": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "adypt_trace_spp_async": (C.c_int, [C.c_void_p, C.c_int]),

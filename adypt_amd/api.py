@@ -434,6 +434,12 @@ class HipPathTracer:
         keys = ("trips", "trip_lanes", "tri_iters", "tri_lanes", "node_phases", "node_lanes", "refills", "empty_trips")
         return dict(zip(keys, [int(v) for v in out]))
 
+    def GetShaderClockGHz(self) -> float:
+        """Clock the chip held under the traversal launches since ResetStats (s_memtime / s_memrealtime of workgroup 0); 0.0 if none ran."""
+        out = (C.c_uint64 * 2)()
+        N.check(N.lib.adypt_get_shader_clock(self._ctx, out), self._ctx)
+        return float(out[0]) / float(out[1]) * 0.1 if out[1] else 0.0
+
     def ResetStats(self) -> None:
         N.check(N.lib.adypt_reset_stats(self._ctx), self._ctx)
 

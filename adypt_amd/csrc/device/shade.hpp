@@ -45,6 +45,7 @@ struct DeviceStats {                           // accumulated until adypt_reset_
 	unsigned long long rays, nodes, tris, hits, shaded, overflows, bad_materials;
 	uint32_t max_stack, pad;
 	unsigned long long wave_profile[8];          // adypt_get_wave_profile (instrumented traversal only)
+	unsigned long long clock_cycles, clock_ticks; // adypt_get_shader_clock: shader cycles / 100 MHz ticks of workgroup 0 over the traversal launches
 };
 
 struct RayStats { int32_t ref_idx; uint32_t nodes, tris, hash, max_depth, pad0, pad1, pad2; }; // 32 B, STATS variant

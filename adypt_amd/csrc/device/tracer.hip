@@ -1284,6 +1284,17 @@ int adypt_get_stats(adypt_ctx *c, adypt_stats *out)
 	return ADYPT_OK;
 }
 
+int adypt_get_shader_clock(adypt_ctx *c, uint64_t out[2])
+{
+	if(!c || !out) return ADYPT_E_INVALID;
+	HIP_TRY(c, hipSetDevice(c->device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	DeviceStats st;
+	HIP_TRY(c, hipMemcpy(&st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+	out[0] = st.clock_cycles; out[1] = st.clock_ticks;
+	return ADYPT_OK;
+}
+
 int adypt_get_wave_profile(adypt_ctx *c, uint64_t out[8])
 {
 	if(!c || !out) return ADYPT_E_INVALID;

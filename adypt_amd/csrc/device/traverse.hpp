@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t fetch_rays(uint32_t seg_len_lanes, uint32_t 
 // ANY = the any-hit overload of the reference (traversal.glsl:257-494, never called by its shaders — SURVEY.md §8 f1):
 // identical traversal, the ray ends at the FIRST accepted triangle in traversal order.
 template <bool STATS, bool ANY = false>
-__global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_trace(TraceArgs a) // hot variant: <= 96 VGPRs
+__global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_trace(TraceArgs a) // hot variant: <= 80 VGPRs, 6 waves per SIMD
 {
 	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64], then the workgroup's ray pool (WgPool)
 	const int lane = threadIdx.x & 63;
@@ -107,6 +107,9 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 	const int home = blockIdx.x & (kNumSegments - 1);
 
 	ADYPT_MEASURE_WAVE_BEGIN();
+	// the clock the chip holds under THIS launch: shader cycles (s_memtime) against the constant 100 MHz counter (s_memrealtime) over the life
+	// of workgroup 0's first wave — bench.py's vector-ALU roof is 1024 SIMDs x this, measured in the run it prices (adypt_get_shader_clock)
+	const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 	if(blockIdx.x == 0 && threadIdx.x == 0)
 	{
 		unsigned long long total = 0;
@@ -495,6 +498,11 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 5)) void k_tra
 		else a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
 	}
 	ADYPT_MEASURE_WAVE_END(a.stats);
+	if(blockIdx.x == 0 && threadIdx.x == 0)
+	{
+		atomicAdd(&a.stats->clock_cycles, __builtin_readcyclecounter() - clk_c0);
+		atomicAdd(&a.stats->clock_ticks, __builtin_amdgcn_s_memrealtime() - clk_r0);
+	}
 	if(any_overflow) atomicAdd(&a.stats->overflows, 1ull);
 	if(STATS)
 	{

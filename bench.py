@@ -68,9 +68,10 @@ def counter_figures(name):
     return pmc, None
 
 
-def valu_roofline(pmc, model, kernel_rays_s):
+def valu_roofline(pmc, model, kernel_rays_s, live_clock_ghz=0.0):
     """The vector-ALU issue roof of the traversal kernel.  Everything is a formula over the committed profiles and ONE live number:
-      peak      = 1024 SIMDs x effective clock; effective clock = GRBM_GUI_ACTIVE / 8 XCDs / launch duration (kernel trace of the same command)
+      peak      = 1024 SIMDs x effective clock; effective clock = shader cycles / 100 MHz ticks sampled inside this run's traversal launches
+                  (fallback: GRBM_GUI_ACTIVE / 8 XCDs / launch duration of the profile run's kernel trace)
       achieved  = issue cycles the kernel's vector-ALU instructions need per second = SQ_INSTS_VALU per ray (profile) x rays/s (live) x the
                   average ARCHITECTURAL issue time of its instruction mix (2 cycles full-rate fp32 / logic / moves, 4 the other classes and
                   packed fp32, 8 transcendental: profiles/r3_valu_issue_model.json)
@@ -79,14 +80,18 @@ def valu_roofline(pmc, model, kernel_rays_s):
     4.33 / 8.24).  That figure exceeds 1 — the kernel's mixed stream issues faster than the weighted sum of single-class loops — so the loops
     are not a roof; it is printed because VERDICT r2 asked for both.  SQ_ACTIVE_INST_VALU is NOT used: the calibration shows it counts 1 per
     instruction (2 per transcendental) whatever the instruction's issue time."""
-    clock = pmc.get("effective_clock_GHz")
+    # the clock: measured inside this run's own traversal launches (s_memtime / s_memrealtime, adypt_get_shader_clock) when available —
+    # boxes of the pool hold 2.1-2.3 GHz under this kernel — otherwise the one of the profile run (GRBM_GUI_ACTIVE / 8 / kernel-trace duration)
+    profile_clock = pmc.get("effective_clock_GHz")
+    clock = live_clock_ghz if live_clock_ghz and live_clock_ghz > 0.5 else profile_clock
     peak = N_SIMD * (clock or NOMINAL_CLOCK_GHZ)
     inst_rate = pmc["valu_insts_per_ray"] * kernel_rays_s
     arch = model["avg_issue_cycles_per_inst_architectural"] if model else 4.0
     achieved = inst_rate * arch / 1e9
     frac = achieved / peak
     out = {"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "Gcycle/s", "frac": round(frac, 4),
-           "effective_clock_GHz": round(clock, 3) if clock else None, "lane_util": round(pmc["lane_util"], 4),
+           "effective_clock_GHz": round(clock, 3) if clock else None, "clock_source": "live: s_memtime / s_memrealtime inside this run's traversal launches" if clock == live_clock_ghz else "profile run",
+           "effective_clock_GHz_in_profile_run": round(profile_clock, 3) if profile_clock else None, "lane_util": round(pmc["lane_util"], 4),
            "useful_frac": round(min(1.0, frac) * pmc["lane_util"], 4),
            "valu_insts_per_ray": round(pmc["valu_insts_per_ray"], 2), "valu_Ginst_s": round(inst_rate / 1e9, 1),
            "issue_cycles_per_inst_architectural": arch, "issue_cycles_available_per_inst": round(peak * 1e9 / inst_rate, 3),
@@ -145,6 +150,7 @@ def hbm_resident_block(args, dev):
     pt.Trace(True, steps)
     wall = time.perf_counter() - t1
     st = pt.GetStats()
+    live_clock = pt.GetShaderClockGHz()
     cs = census(pt, steps, warmup, st["rays"])
     bvh_mb = (len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 52) / 1e6
     achieved = cs["alg_bytes"] / (st["trace_ms"] * 1e-3) / 1e9
@@ -161,7 +167,7 @@ def hbm_resident_block(args, dev):
     pmc, why = counter_figures(PMC_SANMIGUEL)
     if pmc:
         out.update(traffic_fields(pmc, st["rays"], st["trace_launches"], rays_s))
-        valu = valu_roofline(pmc, load_profile(ISSUE_MODEL), rays_s)
+        valu = valu_roofline(pmc, load_profile(ISSUE_MODEL), rays_s, live_clock)
         # what binds here is neither roof alone: the fraction reported is the counter-measured fabric traffic against the HBM peak — a valid
         # fraction (an upper bound on HBM bytes: Infinity-Cache hits are in it); the algorithmic figure exceeds what reaches the fabric because
         # the L2s catch the top of the tree, and the vector ALUs are busy for valu_issue_frac of the cycles
@@ -337,6 +343,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     gather_ms = (time.perf_counter() - t_gather) * 1e3
     st = pt.GetStats()
+    live_clock = pt.GetShaderClockGHz()  # the clock the chip held under the traversal launches of the timed region
     # per-rank breakdown, so that a scaling run can be diagnosed from its own line: every rank fills its own slots, one sum all-reduce
     # hands every rank the whole table (5 x N doubles)
     mine = [elapsed * 1e3, float(st["trace_ms"]), float(st["shade_ms"]), gather_ms, float(st["rays"])]
@@ -377,13 +384,13 @@ def main() -> None:
                 "alg_bytes_per_launch": round(alg_bytes / max(1, trace_launches)), "alg_bytes_per_ray": round(alg_bytes / max(1, cs["rays"]), 1),
                 "nodes_per_ray": round(cs["nodes_visited"] / max(1, cs["rays"]), 2), "tris_per_ray": round(cs["tris_tested"] / max(1, cs["rays"]), 2),
                 "alg_GBs": round(alg_gbs, 1), "alg_frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "hbm_peak_GBs": HBM_PEAK_GBS,
-                "traffic": None}
+                "traffic": None, "shader_clock_GHz_live": round(live_clock, 3)}
     # The PMC counters cannot be read from inside this process: per-ray figures come from the committed rocprofv3 --pmc passes over
     # this very command line (tools/collect_profiles.sh -> profiles/r3_pmc_bench.json), hash-checked against the device sources of this
     # tree, x the rays / time measured here.  N > 1: rank 0 traces an interleaved 1/N of the same pixels with the same kernel.
     pmc, why = counter_figures(PMC_BENCH) if (args.scene, args.width, args.height) == ("sponza", 1920, 1080) else (None, "no committed counter passes for this scene / size")
     if pmc:
-        roofline.update(valu_roofline(pmc, load_profile(ISSUE_MODEL), kernel_rays_s))
+        roofline.update(valu_roofline(pmc, load_profile(ISSUE_MODEL), kernel_rays_s, live_clock))
         roofline.update(traffic_fields(pmc, st["rays"], trace_launches, kernel_rays_s))
         roofline["note"] = ("BVH (nodes + Woop + index) %.0f MB is L2 / Infinity-Cache resident: alg_frac_of_hbm_peak may exceed 1 and is not a fraction of HBM "
                             "traffic (traffic = what the counters saw on the fabric).  What binds is vector-ALU issue, the CU's vector-memory pipeline close behind "

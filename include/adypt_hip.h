@@ -187,6 +187,10 @@ int adypt_reset_stats(adypt_ctx *ctx);
  * summed over those, [4] slab-test phases executed, [5] lanes active summed over those, [6] refill events,
  * [7] trips with no lane holding a ray. */
 int adypt_get_wave_profile(adypt_ctx *ctx, uint64_t out[8]);
+/* New (measurement): out[0] = shader-clock cycles (s_memtime), out[1] = ticks of the constant 100 MHz counter (s_memrealtime), both over the
+ * lifetime of workgroup 0 of every traversal launch since adypt_reset_stats: out[0] / out[1] x 0.1 = the GHz the chip held under the
+ * traversal kernel in THIS run (bench.py prices the vector-ALU roof with it). */
+int adypt_get_shader_clock(adypt_ctx *ctx, uint64_t out[2]);
 
 /* ---- pixel-tile sharding plumbing (multi-GPU: one context per GPU/process, one gather per output frame) ---- */
 /* number of RGBA float4 elements in the compact local radiance buffer (owned blocks x 1024 pixels) */

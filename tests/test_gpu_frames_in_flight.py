@@ -182,3 +182,32 @@ def test_pipeline_of_sub_batches_is_bit_invariant(name, w, h, life, fif, spp, su
             for k in ("rays", "nodes_visited", "tris_tested", "hits", "shaded", "max_stack"):
                 assert st[k] == ref[1][k], (pipes, k)
             assert np.array_equal(tri, ref[2]) and np.array_equal(bits(uv), bits(ref[3]))
+
+
+@pytest.mark.parametrize("name,w,h,life,fif,spp", [("tiny0", 100, 75, 4, 11, 23), ("sibenik", 160, 90, 16, 1, 3), ("tiny0", 96, 64, 2, 32, 33)])
+def test_segment_assignment_of_new_paths_is_bit_invariant(name, w, h, life, fif, spp, scene_cache, sobol_matrices, monkeypatch):
+    """k_gen_primary deals chunks of 256 paths round-robin over the 8 queue segments (default) or gives each segment one contiguous
+    run (ADYPT_GEN_DEAL=0, rounds 1-2): which segment — which XCD — a path lives in is scheduling only.  Image, image 1 and the
+    exact work counters are the oracle's either way, for batches, single frames, and batches that do not fill their last chunk."""
+    results = []
+    for deal in ("1", "0"):
+        monkeypatch.setenv("ADYPT_GEN_DEAL", deal)
+        inst = _instance(scene_cache, name, w, h, {"tmpLifetime": life, "maxBounce": 5, "subpixel": 2})
+        p, c = inst.m_path_tracer, inst.m_config.c
+        p.SetFramesInFlight(fif)
+        p.SetInstrumentation(counters=True)
+        p.ResetStats()
+        p.Trace(True, spp)
+        img, st = p.ReadResult(), p.GetStats()
+        tri, uv = p.ReadHits()
+        results.append((img, st, tri, uv))
+        if deal == "1":
+            osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+            state = O.PathTracerState(c.width, c.height)
+            ost = O.pt_frames(osc, P, O.shift_bytes(31, c.width, c.height), sobol_matrices, state, spp).as_dict()
+            assert np.array_equal(bits(img), bits(state.accum[..., :3]))
+            assert (st["rays"], st["nodes_visited"], st["tris_tested"], st["shaded"]) == (ost["rays"], ost["nodes"], ost["tris"], ost["shaded"])
+        p.destroy()
+    (a_img, a_st, a_tri, a_uv), (b_img, b_st, b_tri, b_uv) = results
+    assert np.array_equal(bits(a_img), bits(b_img)) and np.array_equal(a_tri, b_tri) and np.array_equal(bits(a_uv), bits(b_uv))
+    assert (a_st["rays"], a_st["nodes_visited"], a_st["tris_tested"]) == (b_st["rays"], b_st["nodes_visited"], b_st["tris_tested"])
