@@ -1,3 +1,5 @@
+"""Developer tool (GPU box): the clock the chip holds under the traversal kernel (adypt_get_shader_clock: s_memtime / s_memrealtime sampled inside
+the launches) on the bench scene, the 10 M-triangle scene and for a primary-only launch.  python tools/clock_probe.py"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 from adypt_amd import api, scenes
