@@ -211,3 +211,26 @@ def test_segment_assignment_of_new_paths_is_bit_invariant(name, w, h, life, fif,
     (a_img, a_st, a_tri, a_uv), (b_img, b_st, b_tri, b_uv) = results
     assert np.array_equal(bits(a_img), bits(b_img)) and np.array_equal(a_tri, b_tri) and np.array_equal(bits(a_uv), bits(b_uv))
     assert (a_st["rays"], a_st["nodes_visited"], a_st["tris_tested"]) == (b_st["rays"], b_st["nodes_visited"], b_st["tris_tested"])
+
+
+def test_shade_binning_option_and_shader_clock(scene_cache, sobol_matrices, monkeypatch):
+    """ADYPT_SHADE_BIN=1 (k_shade deals a workgroup's paths to its threads sorted by material class; off by default because it measured
+    slower) is scheduling only: image, image 1 and counters equal the oracle's on the material-zoo scene with textures.  Also: the
+    traversal launches report the shader clock they ran at (adypt_get_shader_clock), a plausible one."""
+    monkeypatch.setenv("ADYPT_SHADE_BIN", "1")
+    inst = _instance(scene_cache, "tiny0", 100, 75, {"tmpLifetime": 3, "maxBounce": 6, "subpixel": 2})
+    p, c = inst.m_path_tracer, inst.m_config.c
+    p.SetFramesInFlight(7)
+    p.SetInstrumentation(counters=True)
+    p.ResetStats()
+    assert p.GetShaderClockGHz() == 0.0  # nothing traced since the reset
+    p.Trace(True, 17)
+    img, st = p.ReadResult(), p.GetStats()
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    state = O.PathTracerState(c.width, c.height)
+    ost = O.pt_frames(osc, P, O.shift_bytes(31, c.width, c.height), sobol_matrices, state, 17).as_dict()
+    assert np.array_equal(bits(img), bits(state.accum[..., :3]))
+    assert (st["rays"], st["nodes_visited"], st["tris_tested"], st["shaded"]) == (ost["rays"], ost["nodes"], ost["tris"], ost["shaded"])
+    ghz = p.GetShaderClockGHz()
+    assert 0.8 < ghz < 3.0, ghz
+    p.destroy()
