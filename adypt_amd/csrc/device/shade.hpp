@@ -418,6 +418,111 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 	px.accum[L] = make_float4(fmaf(old.x, fs, r.x) / fs1, fmaf(old.y, fs, r.y) / fs1, fmaf(old.z, fs, r.z) / fs1, 1.0f);
 }
 
+// FetchInfo (pathtracer.glsl:73-100): what the surface at a hit is made of.  Depends on the hit alone (triangle, u, v) — not on the ray —
+// so the frames of one tmpLifetime group, which share their primary hit, share it too (k_shade_first).
+struct SurfaceInfo { F3 origin, normal, diffuse, specular, emission; int illum0; float shininess, ior; bool bad_mat; };
+__device__ __forceinline__ SurfaceInfo fetch_info(const FrameArgs &f, const SceneArgs &sc, int tri_idx, float tu, float tv)
+{
+	SurfaceInfo s;
+	const TriCore tc = load_tri_core(sc, ADYPT_MEASURE_SHADE_GATHER_INDEX(tri_idx));
+	const float *tri = tc.v;
+	const int matid = __float_as_int(tri[18]);
+	// the hit's geometry before the material is looked at: all five loads of the record are then in flight together (with the
+	// interpolation under the material test the compiler fetched the material id first and the rest one round trip later)
+	const float w = 1.0f - tu - tv;
+	s.normal = normalize3(bary3(tri + 9, tri + 12, tri + 15, tu, tv, w));
+	s.origin = bary3(tri + 0, tri + 3, tri + 6, tu, tv, w);
+	s.bad_mat = matid < 0 || matid >= f.n_mats;
+	s.diffuse = s.specular = s.emission = f3(0, 0, 0); s.illum0 = 0; s.shininess = 0.0f; s.ior = 1.0f;
+	if(!s.bad_mat)
+	{
+		const float4 *mp = sc.materials + (size_t)matid * kMatFloat4;
+		const float4 md = mp[0], me = mp[1], ms = mp[2], mx = mp[3], mt = mp[4];
+		const int dtex = __float_as_int(md.x);
+		s.illum0 = __float_as_int(mx.x); s.shininess = mx.y; s.ior = mx.w;
+		const int4 tex_desc = make_int4(__float_as_int(mt.x), __float_as_int(mt.y), __float_as_int(mt.z), 0);
+		if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) s.diffuse = textured_diffuse(sc, tri_idx, tex_desc, tu, tv, w);
+		else s.diffuse = f3(md.y, md.z, md.w);
+		s.specular = f3(ms.y, ms.z, ms.w);
+		s.emission = f3(me.y, me.z, me.w);
+	}
+	return s;
+}
+
+// The rest of one iteration `b` of Render()'s loop (pathtracer.glsl:101-104, 144-201) at a surface with a valid material: emission picked
+// up, the `illum` switch, the new direction and throughput.  Returns whether the path goes on.
+__device__ __forceinline__ bool respond(const FrameArgs &f, const SurfaceInfo &si, const Rng &rng, int b, F3 &dir, F3 &color, F3 &ret)
+{
+	bool alive = true;
+	F3 normal = si.normal;
+	const F3 diffuse = si.diffuse, specular = si.specular;
+	const int illum0 = si.illum0;
+	const float shininess = si.shininess, ior = si.ior;
+	ret = fma3(color, si.emission, ret);
+	if(illum0 < 6 && dot3(dir, normal) > 0) normal = -normal;
+	int illum = illum0;
+	bool done = false;
+	if(illum == 2)
+	{
+		const float e = shininess * 0.01f;
+		if(e > 0.3f)
+		{
+			const F3 r = reflect3(dir, normal), shv = sample_hemisphere(rng, b, e);
+			dir = align_direction(shv, r);
+			if(dot3(dir, normal) < 0.0f) alive = false;
+			else
+			{
+				const float pw = canon_pow(dot3(dir, r), e);
+				color = color * fma3(specular, pw, diffuse);
+			}
+			done = true;
+		}
+		else illum = 1;
+	}
+	if(!done)
+	{
+		if(illum == 1)
+		{
+			dir = align_direction(sample_hemisphere(rng, b, 0.0f), normal);
+			color = color * diffuse;
+		}
+		else if(illum >= 3 && illum <= 5)
+		{
+			color = color * specular;
+			dir = reflect3(dir, normal);
+		}
+		else if(illum == 6 || illum == 7)
+		{
+			float eta = ior;
+			float cosi = dot3(dir, normal);
+			float fresnel, etai, etat;
+			if(cosi > 0) { etai = eta; etat = 1.0f; }
+			else { etai = 1.0f; etat = eta; normal = -normal; cosi = -cosi; }
+			eta = etai / etat;
+			const float sint = (etai / etat) * sqrtf(gl_max(0.0f, fmaf(-cosi, cosi, 1.0f)));
+			if(sint >= 1.0f) fresnel = 1.0f;
+			else
+			{
+				const float cost = sqrtf(gl_max(0.0f, fmaf(-sint, sint, 1.0f)));
+				const float A = etat * cosi, B = etai * cost, C = etai * cosi, D = etat * cost;
+				const float Rs = (A - B) / (A + B);
+				const float Rp = (C - D) / (C + D);
+				fresnel = fmaf(Rs, Rs, Rp * Rp) * 0.5f;
+			}
+			const float cos2 = fmaf(-(eta * eta), fmaf(-cosi, cosi, 1.0f), 1.0f);
+			float sx, sy; sobol2(rng, b, &sx, &sy);
+			if(cos2 > 0 && sx >= fresnel)
+			{
+				const float k = fmaf(eta, cosi, sqrtf(cos2));
+				dir = normalize3(fma3(normal, k, dir * eta));
+			}
+			else dir = reflect3(dir, normal);
+		}
+	}
+	if(b + 1 >= f.max_bounce) alive = false; // last loop iteration
+	return alive;
+}
+
 // One iteration `b` of the for-loop of Render() (pathtracer.glsl:107-202) for the 256 live paths of queue chunk `chunk` of segment `seg`.
 // store_cache: bounce 0 of a frame that traced its primary rays (pathtracer.glsl:121-127).
 __device__ __forceinline__ void shade_chunk(const FrameArgs &f, const SceneArgs &sc, const QueueArgs &q, const PixelArgs &px, const ShadowArgs &sh, int b,
@@ -473,92 +578,15 @@ __device__ __forceinline__ void shade_chunk(const FrameArgs &f, const SceneArgs 
 		}
 		else
 		{
-			const TriCore tc = load_tri_core(sc, ADYPT_MEASURE_SHADE_GATHER_INDEX(tri_idx));
-			const float *tri = tc.v;
-			const int matid = __float_as_int(tri[18]);
-			// the hit's geometry before the material is looked at: all five loads of the record are then in flight together (with the
-			// interpolation under the material test the compiler fetched the material id first and the rest one round trip later)
-			const float w = 1.0f - tu - tv;
-			F3 normal = normalize3(bary3(tri + 9, tri + 12, tri + 15, tu, tv, w));
-			origin = bary3(tri + 0, tri + 3, tri + 6, tu, tv, w);
-			if(matid < 0 || matid >= f.n_mats) { alive = false; bad_mat = true; }
+			const SurfaceInfo si = fetch_info(f, sc, tri_idx, tu, tv);
+			origin = si.origin;
+			if(si.bad_mat) { alive = false; bad_mat = true; }
 			else
 			{
 				shaded = true;
-				const float4 *mp = sc.materials + (size_t)matid * kMatFloat4;
-				const float4 md = mp[0], me = mp[1], ms = mp[2], mx = mp[3], mt = mp[4];
-				const int dtex = __float_as_int(md.x), illum0 = __float_as_int(mx.x);
-				const float shininess = mx.y, ior = mx.w;
-				const int4 tex_desc = make_int4(__float_as_int(mt.x), __float_as_int(mt.y), __float_as_int(mt.z), 0);
-				F3 diffuse;
-				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) diffuse = textured_diffuse(sc, tri_idx, tex_desc, tu, tv, w);
-				else diffuse = f3(md.y, md.z, md.w);
-				const F3 specular = f3(ms.y, ms.z, ms.w);
-				ret = fma3(color, f3(me.y, me.z, me.w), ret);
-				if(illum0 < 6 && dot3(dir, normal) > 0) normal = -normal;
-
 				const uint8_t *sh = px.shift + (size_t)L * 2;
 				const Rng rng{unorm8_to_float(sh[0]), unorm8_to_float(sh[1]), sobol};
-				int illum = illum0;
-				bool done = false;
-				if(illum == 2)
-				{
-					const float e = shininess * 0.01f;
-					if(e > 0.3f)
-					{
-						const F3 r = reflect3(dir, normal), shv = sample_hemisphere(rng, b, e);
-						dir = align_direction(shv, r);
-						if(dot3(dir, normal) < 0.0f) alive = false;
-						else
-						{
-							const float pw = canon_pow(dot3(dir, r), e);
-							color = color * fma3(specular, pw, diffuse);
-						}
-						done = true;
-					}
-					else illum = 1;
-				}
-				if(!done)
-				{
-					if(illum == 1)
-					{
-						dir = align_direction(sample_hemisphere(rng, b, 0.0f), normal);
-						color = color * diffuse;
-					}
-					else if(illum >= 3 && illum <= 5)
-					{
-						color = color * specular;
-						dir = reflect3(dir, normal);
-					}
-					else if(illum == 6 || illum == 7)
-					{
-						float eta = ior;
-						float cosi = dot3(dir, normal);
-						float fresnel, etai, etat;
-						if(cosi > 0) { etai = eta; etat = 1.0f; }
-						else { etai = 1.0f; etat = eta; normal = -normal; cosi = -cosi; }
-						eta = etai / etat;
-						const float sint = (etai / etat) * sqrtf(gl_max(0.0f, fmaf(-cosi, cosi, 1.0f)));
-						if(sint >= 1.0f) fresnel = 1.0f;
-						else
-						{
-							const float cost = sqrtf(gl_max(0.0f, fmaf(-sint, sint, 1.0f)));
-							const float A = etat * cosi, B = etai * cost, C = etai * cosi, D = etat * cost;
-							const float Rs = (A - B) / (A + B);
-							const float Rp = (C - D) / (C + D);
-							fresnel = fmaf(Rs, Rs, Rp * Rp) * 0.5f;
-						}
-						const float cos2 = fmaf(-(eta * eta), fmaf(-cosi, cosi, 1.0f), 1.0f);
-						float sx, sy; sobol2(rng, b, &sx, &sy);
-						if(cos2 > 0 && sx >= fresnel)
-						{
-							const float k = fmaf(eta, cosi, sqrtf(cos2));
-							dir = normalize3(fma3(normal, k, dir * eta));
-						}
-						else dir = reflect3(dir, normal);
-					}
-				}
-				if(b + 1 >= f.max_bounce) alive = false; // last loop iteration
+				alive = respond(f, si, rng, b, dir, color, ret);
 			}
 		}
 		if(!alive && !escaped) finish_path(f, px, pi, L, ret);
@@ -609,6 +637,97 @@ __global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneAr
 	const uint32_t n_in = q.count_in[seg * kCursorStride];
 	if(chunk * kShadeThreads >= n_in) return; // whole workgroup beyond the segment's live range (uniform exit)
 	shade_chunk(f, sc, q, px, sh, b, store_cache, count_stats, seg, chunk, n_in);
+}
+
+// Bounce 0 of a whole batch in one kernel, one thread per local pixel, looping over the batch's frames (batches only; every frame starts
+// from the cached primary hit of its tmpLifetime group, pathtracer.glsl:113-127).  The frames of a group share camera ray, hit and therefore
+// FetchInfo: the surface is fetched ONCE per pixel and group, and per frame only the material response runs — instead of k_gen_primary
+// writing a ray and a hit per path and k_shade reading them back and gathering the same triangle, material and texels 16 times.
+// Same arithmetic per path as k_gen_primary + k_shade(b = 0) (fetch_info / respond are the very functions k_shade calls); which segment a
+// path lands in is scheduling only.  Not used with the sun-visibility query on (escaped paths need their own queue there).
+__global__ __launch_bounds__(kShadeThreads, 6) void k_shade_first(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int count_stats)
+{
+	const uint32_t L = blockIdx.x * kShadeThreads + threadIdx.x;      // local pixel; a workgroup = four 8x8 tiles
+	int x = 0, y = 0;
+	const bool valid = L < (uint32_t)f.n_local_px && local_pixel_xy(f, sc.local_blocks, (int)L, &x, &y);
+	Rng rng{0.0f, 0.0f, f.sobol};
+	if(valid)
+	{
+		const uint8_t *sh = px.shift + (size_t)L * 2;
+		rng.sx = unorm8_to_float(sh[0]); rng.sy = unorm8_to_float(sh[1]);
+	}
+	SurfaceInfo si;
+	si.origin = si.normal = si.diffuse = si.specular = si.emission = f3(0, 0, 0); si.illum0 = 0; si.shininess = 0.0f; si.ior = 1.0f; si.bad_mat = false;
+	F3 cam_dir = f3(0, 0, 1);
+	bool hit = false;
+	int group_now = -1;
+	unsigned long long n_shaded = 0, n_bad = 0;
+	for(int ordinal = 0; ordinal < f.n_frames; ++ordinal)
+	{
+		const int frame = f.frame_first + ordinal * f.frame_stride;
+		const int group = frame_group(f, frame);
+		if(group != group_now) // (uniform) a new tmpLifetime group: its sub-pixel offset, its cached primary hit, the surface there
+		{
+			group_now = group;
+			if(valid)
+			{
+				const int sub_idx = ((f.spp + frame) / f.tmp_life) % (f.subpixel * f.subpixel);
+				const float unit = 1.0f / (float)f.subpixel;
+				cam_dir = camera_dir(f, x, y, (float)(sub_idx / f.subpixel) * unit, (float)(sub_idx % f.subpixel) * unit);
+				const float4 h = cache_of_group(f, px, group)[L];
+				const int tri_idx = __float_as_int(h.x);
+				hit = tri_idx != -1;
+				if(hit) si = fetch_info(f, sc, tri_idx, h.y, h.z);
+			}
+		}
+		const int pi = frame * f.n_local_px + (int)L;
+		bool alive = valid;
+		F3 dir = cam_dir, color = f3(1.0f, 1.0f, 1.0f), ret = f3(0, 0, 0);
+		if(valid)
+		{
+			if(!hit) { ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); alive = false; }
+			else if(si.bad_mat) { alive = false; ++n_bad; }
+			else
+			{
+				++n_shaded;
+				Rng r = rng; r.sobol = f.sobol + frame * 64;
+				alive = respond(f, si, r, 0, dir, color, ret);
+			}
+			if(!alive) finish_path(f, px, pi, (int)L, ret);
+		}
+		// the (frame, workgroup) chunks of the pass are dealt round-robin to the segments: even load, and never more chunks in a segment than
+		// the pass's capacity ceil(chunks / 8) (tracer.hip: seg_slots_for)
+		const uint32_t seg = ((uint32_t)ordinal * gridDim.x + blockIdx.x) & (kNumSegments - 1);
+		const uint32_t slot = append_slot(alive, q.count_out + seg * kCursorStride, seg * q.seg_cap);
+		if(alive)
+		{
+			st3(q.out_o, slot, si.origin.x, si.origin.y, si.origin.z);
+			bool parked = false;
+			if(__float_as_uint(ret.x) != 0u || __float_as_uint(ret.y) != 0u || __float_as_uint(ret.z) != 0u)
+			{
+				f.done[pi] = make_float4(ret.x, ret.y, ret.z, 0.0f);
+				parked = true;
+			}
+			q.out_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)pi | (parked ? kPathParked : 0u)));
+			st3(q.out_col, slot, color.x, color.y, color.z);
+		}
+	}
+	// statistics: one count per path-bounce as in k_shade, summed over the frames first
+	{
+		const unsigned long long mb = __ballot(n_bad != 0);
+		if(mb)
+		{
+			unsigned long long t = n_bad;
+			for(int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+			if((threadIdx.x & 63) == 0) atomicAdd(&px.stats->bad_materials, t);
+		}
+		if(count_stats)
+		{
+			unsigned long long t = n_shaded;
+			for(int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+			if((threadIdx.x & 63) == 0 && t) atomicAdd(&px.stats->shaded, t);
+		}
+	}
 }
 
 // pathtracer.glsl:130-135 with the commented-out condition enabled: the escaped path receives the sun term only if the

@@ -116,6 +116,7 @@ struct adypt_ctx {
 	// launch geometry of the persistent traversal kernel
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0, occupancy_api = 0;
 	uint32_t refill_min = kRefillMin, chunk = kChunk, bite = kBite, endgame = kEndgame;
+	int first_fused = 1;           // ADYPT_FIRST_FUSED=0: camera rays and bounce 0 of a batch as k_gen_primary + k_shade (rounds 1-2)
 	int deal_chunks = 1;           // k_gen_primary deals 256-path chunks round-robin to the 8 queue segments (ADYPT_GEN_DEAL=0: one contiguous run each)
 
 	// state
@@ -639,6 +640,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	c->num_cus = prop.multiProcessorCount;
 	if(const char *ov = getenv("ADYPT_REFILL_MIN")) c->refill_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_GEN_DEAL")) c->deal_chunks = atoi(ov) != 0;
+	if(const char *ov = getenv("ADYPT_FIRST_FUSED")) c->first_fused = atoi(ov) != 0;
 	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_ENDGAME")) c->endgame = (uint32_t)std::max(0, std::min(1024, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_BITE")) c->bite = (uint32_t)std::max(1, std::min(4096, atoi(ov)));
@@ -1067,6 +1069,9 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		// maxBounce on pipe k's stream in window k of the queues.  Everything before this point (Sobol upload, primary-only
 		// pass, the previous batch's k_resolve) is ordered before every chain by the fork event, every chain before k_resolve.
 		const int n_pipes = m > 1 ? std::max(1, std::min(std::min(c->pipeline, kMaxPipes), m)) : 1;
+		// batches start every frame from a cached primary hit: camera rays and bounce 0 in one kernel (k_shade_first) unless the escaped paths
+		// need the sun-visibility queue
+		const bool fused_first = m > 1 && use_cache && !c->sun_visibility && c->first_fused;
 		// the counters of all pipes are contiguous: one clearing launch, on the context's stream, before the chains fork
 		clear_counters(c, c->d_counters, n_pipes, c->stream);
 		if(n_pipes > 1)
@@ -1085,12 +1090,21 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			sub[k].grid = (int)(kNumSegments * (pass_seg_paths(c, sub[k].win, frames_k) / kShadeThreads)); // kNumSegments x chunks per segment
 			frame0 += frames_k;
 			const Pipe &pipe = c->pipes[k];
-			QueueArgs q = queue_args(c, sub[k].win, 1, pipe.counters->count[0], pipe.counters->count[0], frames_k); // out = queue 0
 			hipEvent_t *stop = begin_timing(c, 1, pipe.stream);
-			hipLaunchKernelGGL(k_gen_primary, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, use_cache, 1);
+			if(fused_first)
+			{
+				// camera rays + bounce 0 of every frame from the cached primary hits, the surface fetched once per pixel and tmpLifetime group
+				QueueArgs q = queue_args(c, sub[k].win, 0, pipe.counters->count[0], pipe.counters->count[1], frames_k); // out = queue 1 = bounce 1's rays
+				hipLaunchKernelGGL(k_shade_first, dim3((unsigned)(c->n_local_px / kShadeThreads)), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, stats ? 1 : 0);
+			}
+			else
+			{
+				QueueArgs q = queue_args(c, sub[k].win, 1, pipe.counters->count[0], pipe.counters->count[0], frames_k); // out = queue 0
+				hipLaunchKernelGGL(k_gen_primary, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, use_cache, 1);
+			}
 			end_timing(stop, pipe.stream);
 		}
-		for(int b = 0; b < max_bounce; ++b)
+		for(int b = fused_first ? 1 : 0; b < max_bounce; ++b)
 		{
 			const int in = b & 1;
 			for(int k = 0; k < n_pipes; ++k) // bounce by bounce over the pipes: their launches reach the GPU interleaved

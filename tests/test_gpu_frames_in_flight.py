@@ -187,11 +187,13 @@ def test_pipeline_of_sub_batches_is_bit_invariant(name, w, h, life, fif, spp, su
 @pytest.mark.parametrize("name,w,h,life,fif,spp", [("tiny0", 100, 75, 4, 11, 23), ("sibenik", 160, 90, 16, 1, 3), ("tiny0", 96, 64, 2, 32, 33)])
 def test_segment_assignment_of_new_paths_is_bit_invariant(name, w, h, life, fif, spp, scene_cache, sobol_matrices, monkeypatch):
     """k_gen_primary deals chunks of 256 paths round-robin over the 8 queue segments (default) or gives each segment one contiguous
-    run (ADYPT_GEN_DEAL=0, rounds 1-2): which segment — which XCD — a path lives in is scheduling only.  Image, image 1 and the
+    run (ADYPT_GEN_DEAL=0, rounds 1-2): which segment — which XCD — a path lives in is scheduling only.  Likewise bounce 0 of a batch in
+    one kernel with the surface fetched once per pixel and tmpLifetime group (k_shade_first, default) or as k_gen_primary + k_shade.  Image, image 1 and the
     exact work counters are the oracle's either way, for batches, single frames, and batches that do not fill their last chunk."""
     results = []
     for deal in ("1", "0"):
         monkeypatch.setenv("ADYPT_GEN_DEAL", deal)
+        monkeypatch.setenv("ADYPT_FIRST_FUSED", deal)  # "0": camera rays and bounce 0 of a batch as k_gen_primary + k_shade instead of k_shade_first
         inst = _instance(scene_cache, name, w, h, {"tmpLifetime": life, "maxBounce": 5, "subpixel": 2})
         p, c = inst.m_path_tracer, inst.m_config.c
         p.SetFramesInFlight(fif)
