@@ -1,0 +1,444 @@
+// k_path — bounces 1 .. maxBounce-1 of a whole batch in ONE persistent launch: the reference's for(b < uMaxBounce) loop inside a single
+// dispatch (shaders/pathtracer.glsl:107-202, src/Tracer/OglPathTracer.cpp:60) instead of [k_trace -> k_shade] per bounce.
+//
+// Why: every persistent traversal launch ends with its longest rays (~0.1 ms with the chip draining, profiles/r3_ablations_k_trace.txt item 14);
+// seven of those per batch are 2-3 % of a 1-GPU batch and the whole strong-scaling loss of a pixel-tile shard; and k_shade, on its own,
+// waits on its gathers with half the vector ALUs idle while ~1 GB of queue records per frame travel through HBM between the two kernels.
+//
+// How (results unchanged: per-path arithmetic is fetch_info / respond / finish_path of shade.hpp and the trip of traverse_trip.inc, and
+// k_resolve applies the finished samples in frame order):
+//   * a workgroup owns kPathSlots PATHS for their whole life, kept in an LDS table (path word, direction, throughput, and origin-or-hit:
+//     40 bytes) — more paths than lanes, so a lane whose ray has finished finds the next ray waiting;
+//   * a lane traverses the ray of one path slot.  When >= refill_min lanes of a wave are idle the wave DEPOSITS its finished rays (hit into
+//     the slot, slot index onto the workgroup's to-shade list) and takes ready rays off the to-trace list — LDS only, a short spin lock;
+//   * whichever wave finds >= shade_min deposited hits takes 64 of them and runs one bounce of Render() for them with all 64 lanes —
+//     FetchInfo, the illum switch, accumulate on termination: exactly k_shade's work at k_shade's lane occupancy — while the other waves
+//     of the CU keep traversing and hide its gather latency; its own rays simply wait in their registers;
+//   * a path that ends is replaced from the global queue (the bounce-1 rays k_shade_first wrote) by the shading wave itself: one device
+//     atomic per shading round, issued BEFORE the gathers for the paths that are certain to end (miss, last bounce) so that its latency is hidden;
+//   * no inter-workgroup communication of any kind, so none of the cross-XCD visibility questions of a streaming queue.
+// The kernel ends when the global queue is dry and every workgroup has finished the paths it holds.
+#pragma once
+#include "traverse.hpp"
+
+namespace adypt {
+
+constexpr int kPathSlots = 384;                  // paths a workgroup holds (256 lanes + 128 ready or waiting to be shaded)
+constexpr int kTabFields = 10;                   // path word | direction | throughput | origin (to-trace) or hit (to-shade)
+constexpr int kParkDwords = 21;                  // per-lane ray state a shading wave parks in LDS (so that the shading code has the registers)
+constexpr uint32_t kPwBounceShift = 26;          // path word in the table: bits 25..0 path id, 30..26 bounce index, 31 radiance parked
+constexpr uint32_t kPwIdMask = (1u << kPwBounceShift) - 1u;
+constexpr int64_t kPathMaxPaths = (int64_t)1 << kPwBounceShift; // batches with more paths keep the launch-per-bounce pipeline
+enum { T_PW = 0, T_DX, T_DY, T_DZ, T_CX, T_CY, T_CZ, T_OX, T_OY, T_OZ };
+
+struct PathCtl {                                 // workgroup control block in LDS (zeroed at start)
+	uint32_t n_shade, n_trace, live, busy;         // deposited hits, ready rays, paths alive in this workgroup, a wave is shading   <- one 16-byte peek
+	uint32_t lock, rays, shaded, init_have;
+	uint32_t pad1[8];
+};
+
+struct PathArgs {
+	const uint4 *nodes;
+	const float4 *woop;
+	const int32_t *tri_indices;
+	const float *in_o; const float4 *in_d; const float *in_col; // the batch's ray queue as k_shade_first leaves it (12 / 16 / 12 bytes per path)
+	RayStats *ray_stats;           // always null (traverse_trip.inc's per-ray record belongs to adypt_trace_rays)
+	const uint32_t *count;         // paths per queue segment: count[s * kCursorStride]
+	uint32_t *cursor;              // fetch cursor per segment, zero at launch
+	uint2 *spill;                  // [(stack_size - lds_depth)][total lanes]
+	DeviceStats *stats;
+	uint32_t seg_cap;
+	int32_t stack_size, lds_depth;
+	uint32_t refill_min, shade_min;
+	int32_t b0;                    // bounce index of the queue's rays (1: k_shade_first did bounce 0)
+	float tmin;
+};
+
+inline size_t path_lds_bytes(int lds_depth)
+{
+	return (size_t)(kTraceThreads / 64) * (size_t)lds_depth * 64 * sizeof(uint2) + (size_t)kTabFields * kPathSlots * 4 + (size_t)kParkDwords * 64 * 4 + 2 * (size_t)kPathSlots * 2 +
+	       sizeof(PathCtl);
+}
+
+__device__ __forceinline__ void wg_lock(PathCtl *ctl, int lane)
+{
+	if(lane == 0)
+	{
+		uint32_t expect = 0u;
+		while(!__hip_atomic_compare_exchange_strong(&ctl->lock, &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+		{
+			expect = 0u;
+			__builtin_amdgcn_s_sleep(1);
+		}
+	}
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void wg_unlock(PathCtl *ctl, int lane)
+{
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (one wave's LDS operations execute in order; this keeps the compiler from moving them)
+	if(lane == 0) __hip_atomic_store(&ctl->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+#ifndef ADYPT_PATH_WAVES
+#define ADYPT_PATH_WAVES 6  // waves per SIMD the register allocation is held to (6: <= 80 VGPRs, like k_trace)
+#endif
+
+template <bool STATS>
+__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathArgs a, FrameArgs f, SceneArgs sc, PixelArgs px, int count_stats)
+{
+	constexpr bool ANY = false;
+	constexpr bool kUniformTmin = true; // every ray of the pass has the pass's tmin
+	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64] | path table [kTabFields][kPathSlots] | parking [kParkDwords][64] | to-shade, to-trace lists | PathCtl
+	const int lane = threadIdx.x & 63;
+	const int wave = threadIdx.x >> 6;
+	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
+	uint32_t *tab = (uint32_t *)(lds_stack + (size_t)(kTraceThreads / 64) * a.lds_depth * 64);
+	uint32_t *park = tab + kTabFields * kPathSlots;
+	uint16_t *to_shade = (uint16_t *)(park + kParkDwords * 64), *to_trace = to_shade + kPathSlots;
+	PathCtl *ctl = (PathCtl *)(to_trace + kPathSlots);
+	const uint32_t total_lanes = gridDim.x * blockDim.x;
+	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+	const int home = blockIdx.x & (kNumSegments - 1);
+	const float tmin = a.tmin;
+
+	const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+	if(threadIdx.x < sizeof(PathCtl) / 4) ((uint32_t *)ctl)[threadIdx.x] = 0u;
+	__syncthreads();
+
+	const uint32_t seg_len_lanes = lane < kNumSegments ? a.count[lane * kCursorStride] : 0u;
+	uint32_t seg_done = 0;              // wave-uniform: segments found empty or exhausted
+	for(int sgm = 0; sgm < kNumSegments; ++sgm)
+		if(__builtin_amdgcn_readlane((int)seg_len_lanes, sgm) == 0) seg_done |= 1u << sgm;
+
+	// a path of the global queue moves into table slot `slot`
+	auto load_path = [&](uint32_t idx, uint32_t slot) {
+		const F3 o = ld3(a.in_o, idx);
+		const float4 d4 = a.in_d[idx];
+		const F3 c3 = ld3(a.in_col, idx);
+		const uint32_t w = __float_as_uint(d4.w); // path word of the queue: bits 30..0 path id (< 2^26 here), bit 31 radiance parked
+		tab[T_PW * kPathSlots + slot] = (w & (kPathParked | kPwIdMask)) | ((uint32_t)a.b0 << kPwBounceShift);
+		tab[T_DX * kPathSlots + slot] = __float_as_uint(d4.x); tab[T_DY * kPathSlots + slot] = __float_as_uint(d4.y); tab[T_DZ * kPathSlots + slot] = __float_as_uint(d4.z);
+		tab[T_CX * kPathSlots + slot] = __float_as_uint(c3.x); tab[T_CY * kPathSlots + slot] = __float_as_uint(c3.y); tab[T_CZ * kPathSlots + slot] = __float_as_uint(c3.z);
+		tab[T_OX * kPathSlots + slot] = __float_as_uint(o.x); tab[T_OY * kPathSlots + slot] = __float_as_uint(o.y); tab[T_OZ * kPathSlots + slot] = __float_as_uint(o.z);
+	};
+
+	// ---------------- the workgroup's first paths: wave 0 reserves them, every thread moves its share into the table ----------------
+	{
+		uint32_t *init_idx = (uint32_t *)lds_stack; // (the stacks are not in use yet)
+		if(wave == 0)
+		{
+			uint32_t have = 0;
+			while(have < (uint32_t)kPathSlots)
+			{
+				uint32_t gb = 0, left = 0;
+				const uint32_t gn = fetch_rays(seg_len_lanes, seg_done, a.cursor, a.seg_cap, home, (uint32_t)kPathSlots - have, &gb, &left);
+				if(gn == 0) break;
+				for(uint32_t i = (uint32_t)lane; i < gn; i += 64u) init_idx[have + i] = gb + i;
+				have += gn;
+			}
+			if(lane == 0) { ctl->live = have; ctl->init_have = have; ctl->n_trace = have > (uint32_t)kTraceThreads ? have - (uint32_t)kTraceThreads : 0u; }
+		}
+		__syncthreads();
+		const uint32_t have = ctl->init_have;
+		uint32_t i0 = 0, i1 = 0;
+		if(threadIdx.x < have) i0 = init_idx[threadIdx.x];
+		if(threadIdx.x + kTraceThreads < have) i1 = init_idx[threadIdx.x + kTraceThreads];
+		__syncthreads(); // the stack area is free again
+		if(threadIdx.x < have) load_path(i0, threadIdx.x);
+		if(threadIdx.x + kTraceThreads < have) { load_path(i1, threadIdx.x + kTraceThreads); to_trace[threadIdx.x] = (uint16_t)(threadIdx.x + kTraceThreads); }
+		__syncthreads(); // slots beyond the lanes are on the to-trace list before any wave looks at it
+	}
+
+	// per-lane ray state (the names traverse_trip.inc works on)
+	bool active = false;
+	uint32_t ray = threadIdx.x;                  // the path slot whose ray this lane traverses
+	bool setup = threadIdx.x < ctl->init_have;   // the lane starts the ray of slot `ray` at the top of the loop
+	V2 od_x = v2(0, 0), od_y = v2(0, 0), od_z = v2(0, 1);
+	F3 idir = f3(0, 0, 1);
+	bool nx = false, ny = false, nz = false;
+	uint32_t octinv = 7u;
+	float hit_t = 1e9f, hit_u = 0.0f, hit_v = 0.0f;
+	int32_t hit_idx = -1;
+	int sp = 0;
+	uint32_t ng_x = 0, ng_y = 0, tg_x = 0, tg_y = 0;
+	uint32_t n_nodes = 0, n_tris = 0, hash = 0, max_depth = 0;
+	bool overflow = false;
+	bool flush = false;
+	bool pending = false;
+	uint32_t node = 0, depth_after_push = 0;
+	bool push_overflow = false;
+	unsigned long long st_nodes = 0, st_tris = 0, st_hits = 0;
+	uint32_t st_maxdepth = 0;
+	bool any_overflow = false;
+	uint32_t wave_rays = 0, wave_shaded = 0, wave_bad = 0; // wave-uniform totals, added up per workgroup at the end
+	unsigned long long wp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	auto wave_event = [&](int slot) {
+		const unsigned long long m = __ballot(true);
+		if(lane == (int)__builtin_ctzll(m)) { wp[slot] += 1; wp[slot + 1] += (unsigned long long)__popcll(m); }
+	};
+
+	for(;;)
+	{
+		// ---------------- start the rays of the slots the lanes have just taken (traversal.glsl:16-35) ----------------
+		const unsigned long long starting = __ballot(setup);
+		if(starting)
+		{
+			if(setup)
+			{
+				const float ox = __uint_as_float(tab[T_OX * kPathSlots + ray]), oy = __uint_as_float(tab[T_OY * kPathSlots + ray]), oz = __uint_as_float(tab[T_OZ * kPathSlots + ray]);
+				F3 dir = f3(__uint_as_float(tab[T_DX * kPathSlots + ray]), __uint_as_float(tab[T_DY * kPathSlots + ray]), __uint_as_float(tab[T_DZ * kPathSlots + ray]));
+				const float ooeps = __uint_as_float((127u - 64u) << 23);
+				dir.x = fabsf(dir.x) > ooeps ? dir.x : (dir.x >= 0 ? ooeps : -ooeps);
+				dir.y = fabsf(dir.y) > ooeps ? dir.y : (dir.y >= 0 ? ooeps : -ooeps);
+				dir.z = fabsf(dir.z) > ooeps ? dir.z : (dir.z >= 0 ? ooeps : -ooeps);
+				dir = normalize3(dir);
+				idir = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+				nx = dir.x < 0; ny = dir.y < 0; nz = dir.z < 0;
+				octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
+				od_x = v2(ox, dir.x); od_y = v2(oy, dir.y); od_z = v2(oz, dir.z);
+				hit_t = 1e9f; hit_u = 0.0f; hit_v = 0.0f; hit_idx = -1;
+				sp = 0;
+				ng_x = 0; ng_y = 0x80000000u; tg_x = 0; tg_y = 0;
+				if(STATS) { n_nodes = 0; n_tris = 0; hash = 0x811c9dc5u; max_depth = 0; }
+				overflow = false; pending = false; push_overflow = false; depth_after_push = 0;
+				active = true;
+				setup = false;
+			}
+			wave_rays += (uint32_t)__popcll(starting);
+		}
+
+		// ---------------- exchange with the workgroup: deposit finished rays, shade a batch, take ready rays ----------------
+		const unsigned long long idle = __ballot(!active);
+		const uint32_t n_idle = (uint32_t)__popcll(idle);
+		if(n_idle >= a.refill_min)
+		{
+			const unsigned long long fl = __ballot(flush);
+			const uint32_t n_flush = (uint32_t)__popcll(fl);
+			// a look at the lists without the lock (a hint: everything is decided again under it)
+			asm volatile("" ::: "memory"); // (read the control block afresh)
+			const uint4 pk = *(const uint4 *)&ctl->n_shade;
+			const uint32_t pk_shade = uni(pk.x), pk_trace = uni(pk.y), pk_live = uni(pk.z), pk_busy = uni(pk.w);
+			const uint32_t pk_thr = min(a.shade_min, max(1u, pk_live >> 2));
+			if(n_flush != 0u || pk_trace != 0u || (pk_shade + n_flush >= pk_thr && !pk_busy))
+			{
+				// deposit, first half (no lock: the slot is this lane's until it is on the list): remap and hit (traversal.glsl:253-254)
+				if(flush)
+				{
+					int32_t tri = -1;
+					if(hit_idx != -1) tri = a.tri_indices[hit_idx];
+					tab[T_OX * kPathSlots + ray] = (uint32_t)tri; tab[T_OY * kPathSlots + ray] = __float_as_uint(hit_u); tab[T_OZ * kPathSlots + ray] = __float_as_uint(hit_v);
+				}
+				const uint32_t fl_rank = lane_rank(fl), idle_rank = lane_rank(idle);
+				wg_lock(ctl, lane);
+				uint32_t n_s = uni(ctl->n_shade), n_t = uni(ctl->n_trace);
+				const uint32_t lv = uni(ctl->live);
+				if(flush) to_shade[n_s + fl_rank] = (uint16_t)ray;
+				n_s += n_flush;
+				flush = false;
+				const uint32_t thr = min(a.shade_min, max(1u, lv >> 2)); // fewer than 4 batches of paths left: smaller batches, down to single paths
+				const bool do_shade = n_s >= thr && n_s != 0u && uni(ctl->busy) == 0u; // one shading wave per workgroup at a time (one parking area)
+				uint32_t take = 0, sslot = 0;
+				if(do_shade)
+				{
+					take = min(64u, n_s);
+					n_s -= take;
+					if((uint32_t)lane < take) sslot = to_shade[n_s + (uint32_t)lane];
+					if(lane == 0) ctl->busy = 1u;
+				}
+				else
+				{
+					const uint32_t got = min(n_idle, n_t);
+					n_t -= got;
+					if(!active && idle_rank < got) { ray = to_trace[n_t + idle_rank]; setup = true; }
+					if(lane == 0) ctl->n_trace = n_t;
+				}
+				if(lane == 0) ctl->n_shade = n_s;
+				wg_unlock(ctl, lane);
+
+				if(do_shade)
+				{
+					// ---------------- one iteration of Render()'s loop (pathtracer.glsl:107-202) for `take` paths, one per lane ----------------
+					// The wave's own rays wait.  Their state is parked in LDS for the duration: the shading code then has the registers the
+					// traversal loop lives in (the loop itself is register-allocated exactly as in k_trace).
+					uint32_t *pk_lane = park + lane;
+					pk_lane[0 * 64] = __float_as_uint(od_x.x); pk_lane[1 * 64] = __float_as_uint(od_x.y); pk_lane[2 * 64] = __float_as_uint(od_y.x); pk_lane[3 * 64] = __float_as_uint(od_y.y);
+					pk_lane[4 * 64] = __float_as_uint(od_z.x); pk_lane[5 * 64] = __float_as_uint(od_z.y);
+					pk_lane[6 * 64] = __float_as_uint(idir.x); pk_lane[7 * 64] = __float_as_uint(idir.y); pk_lane[8 * 64] = __float_as_uint(idir.z);
+					pk_lane[9 * 64] = __float_as_uint(hit_t); pk_lane[10 * 64] = __float_as_uint(hit_u); pk_lane[11 * 64] = __float_as_uint(hit_v); pk_lane[12 * 64] = (uint32_t)hit_idx;
+					pk_lane[13 * 64] = (uint32_t)sp; pk_lane[14 * 64] = ng_x; pk_lane[15 * 64] = ng_y; pk_lane[16 * 64] = tg_x; pk_lane[17 * 64] = tg_y;
+					pk_lane[18 * 64] = node; pk_lane[19 * 64] = ray; pk_lane[20 * 64] = octinv;
+					asm volatile("" ::: "memory");
+					const bool have = (uint32_t)lane < take;
+					uint32_t pw = 0;
+					F3 dir = f3(0, 0, 1), color = f3(0, 0, 0), origin = f3(0, 0, 0), ret = f3(0, 0, 0), ret_in = f3(0, 0, 0);
+					int32_t tri_idx = -1;
+					float tu = 0.0f, tv = 0.0f;
+					if(have)
+					{
+						pw = tab[T_PW * kPathSlots + sslot];
+						dir = f3(__uint_as_float(tab[T_DX * kPathSlots + sslot]), __uint_as_float(tab[T_DY * kPathSlots + sslot]), __uint_as_float(tab[T_DZ * kPathSlots + sslot]));
+						color = f3(__uint_as_float(tab[T_CX * kPathSlots + sslot]), __uint_as_float(tab[T_CY * kPathSlots + sslot]), __uint_as_float(tab[T_CZ * kPathSlots + sslot]));
+						tri_idx = (int32_t)tab[T_OX * kPathSlots + sslot]; tu = __uint_as_float(tab[T_OY * kPathSlots + sslot]); tv = __uint_as_float(tab[T_OZ * kPathSlots + sslot]);
+					}
+					const int b = (int)((pw >> kPwBounceShift) & 31u);
+					const int pi = (int)(pw & kPwIdMask);
+					bool parked = (pw & kPathParked) != 0u;
+					// the paths that are certain to end here (miss, or this is the last bounce) are replaced from the global queue: their
+					// reservation is issued now and is back by the time the gathers below have returned
+					const bool sure = have && (tri_idx == -1 || b + 1 >= f.max_bounce);
+					const uint32_t n_sure = (uint32_t)__popcll(__ballot(sure));
+					const bool early = n_sure != 0u && !((seg_done >> home) & 1u);
+					uint32_t rel = 0;
+					if(early && lane == 0) rel = atomicAdd(&a.cursor[home * kCursorStride], n_sure);
+
+					bool alive = have, shaded = false, bad_mat = false;
+					int L = 0;
+					if(have)
+					{
+						const int frame = (int)((uint32_t)pi / (uint32_t)f.n_local_px);
+						L = pi - frame * f.n_local_px;
+						if(parked) { const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); }
+						ret_in = ret;
+						if(tri_idx == -1)
+						{
+							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135
+							alive = false;
+						}
+						else
+						{
+							const SurfaceInfo si = fetch_info(f, sc, tri_idx, tu, tv);
+							origin = si.origin;
+							if(si.bad_mat) { alive = false; bad_mat = true; }
+							else
+							{
+								shaded = true;
+								const uint8_t *shb = px.shift + (size_t)L * 2;
+								const Rng rng{unorm8_to_float(shb[0]), unorm8_to_float(shb[1]), f.sobol + frame * 64};
+								alive = respond(f, si, rng, b, dir, color, ret);
+							}
+						}
+						if(!alive) finish_path(f, px, pi, L, ret);
+					}
+					wave_bad += (uint32_t)__popcll(__ballot(bad_mat));
+					if(count_stats) wave_shaded += (uint32_t)__popcll(__ballot(shaded));
+					if(alive)
+					{
+						if(__float_as_uint(ret.x) != __float_as_uint(ret_in.x) || __float_as_uint(ret.y) != __float_as_uint(ret_in.y) ||
+						   __float_as_uint(ret.z) != __float_as_uint(ret_in.z))
+						{
+							f.done[pi] = make_float4(ret.x, ret.y, ret.z, 0.0f); // radiance picked up on the way: parked per path (shade.hpp)
+							parked = true;
+						}
+						tab[T_PW * kPathSlots + sslot] = (uint32_t)pi | ((uint32_t)(b + 1) << kPwBounceShift) | (parked ? kPathParked : 0u);
+						tab[T_DX * kPathSlots + sslot] = __float_as_uint(dir.x); tab[T_DY * kPathSlots + sslot] = __float_as_uint(dir.y); tab[T_DZ * kPathSlots + sslot] = __float_as_uint(dir.z);
+						tab[T_CX * kPathSlots + sslot] = __float_as_uint(color.x); tab[T_CY * kPathSlots + sslot] = __float_as_uint(color.y); tab[T_CZ * kPathSlots + sslot] = __float_as_uint(color.z);
+						tab[T_OX * kPathSlots + sslot] = __float_as_uint(origin.x); tab[T_OY * kPathSlots + sslot] = __float_as_uint(origin.y); tab[T_OZ * kPathSlots + sslot] = __float_as_uint(origin.z);
+					}
+					// ---------------- paths that ended: their slots take the next paths of the global queue ----------------
+					const bool dead = have && !alive;
+					const unsigned long long dl = __ballot(dead);
+					const uint32_t n_dead = (uint32_t)__popcll(dl), dead_rank = lane_rank(dl);
+					bool repl = false;
+					uint32_t idx = 0;
+					{
+						uint32_t served = 0;
+						if(early)
+						{
+							rel = uni(rel);
+							const uint32_t seg_len = (uint32_t)__builtin_amdgcn_readlane((int)seg_len_lanes, home);
+							if(rel < seg_len)
+							{
+								served = min(n_sure, seg_len - rel);
+								if(dead && dead_rank < served) { idx = (uint32_t)home * a.seg_cap + rel + dead_rank; repl = true; }
+							}
+							if(rel + n_sure >= seg_len) seg_done |= 1u << home;
+						}
+						while(served < n_dead) // (wave-uniform) the rest: paths that ended unexpectedly, or the home segment has run out
+						{
+							uint32_t gb = 0, left = 0;
+							const uint32_t gn = fetch_rays(seg_len_lanes, seg_done, a.cursor, a.seg_cap, home, n_dead - served, &gb, &left);
+							if(gn == 0) break;
+							if(dead && dead_rank >= served && dead_rank < served + gn) { idx = gb + (dead_rank - served); repl = true; }
+							served += gn;
+						}
+					}
+					if(repl) load_path(idx, sslot);
+					// every global store of this round (finished samples, parked radiance) has left before another wave of the workgroup can
+					// shade these paths again (same CU, same L1: no more is needed inside a workgroup)
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					const bool push = have && (alive || repl);
+					const unsigned long long pm = __ballot(push);
+					const uint32_t n_push = (uint32_t)__popcll(pm), push_rank = lane_rank(pm);
+					const uint32_t n_lost = n_dead - (uint32_t)__popcll(__ballot(repl));
+					// the wave's own rays come back
+					asm volatile("" ::: "memory");
+					od_x = v2(__uint_as_float(pk_lane[0 * 64]), __uint_as_float(pk_lane[1 * 64])); od_y = v2(__uint_as_float(pk_lane[2 * 64]), __uint_as_float(pk_lane[3 * 64]));
+					od_z = v2(__uint_as_float(pk_lane[4 * 64]), __uint_as_float(pk_lane[5 * 64]));
+					idir = f3(__uint_as_float(pk_lane[6 * 64]), __uint_as_float(pk_lane[7 * 64]), __uint_as_float(pk_lane[8 * 64]));
+					hit_t = __uint_as_float(pk_lane[9 * 64]); hit_u = __uint_as_float(pk_lane[10 * 64]); hit_v = __uint_as_float(pk_lane[11 * 64]); hit_idx = (int32_t)pk_lane[12 * 64];
+					sp = (int)pk_lane[13 * 64]; ng_x = pk_lane[14 * 64]; ng_y = pk_lane[15 * 64]; tg_x = pk_lane[16 * 64]; tg_y = pk_lane[17 * 64];
+					node = pk_lane[18 * 64]; ray = pk_lane[19 * 64]; octinv = pk_lane[20 * 64];
+					wg_lock(ctl, lane);
+					n_t = uni(ctl->n_trace);
+					if(push) to_trace[n_t + push_rank] = (uint16_t)sslot;
+					n_t += n_push;
+					const uint32_t got = min(n_idle, n_t); // and the wave's own idle lanes take the first of them
+					n_t -= got;
+					if(!active && idle_rank < got) { ray = to_trace[n_t + idle_rank]; setup = true; }
+					if(lane == 0) { ctl->n_trace = n_t; if(n_lost) ctl->live = ctl->live - n_lost; ctl->busy = 0u; }
+					wg_unlock(ctl, lane);
+				}
+				if(__ballot(setup)) continue;
+			}
+		}
+		const unsigned long long live = __ballot(active);
+		if(STATS && lane == 0) { wp[0] += 1; wp[1] += (unsigned long long)__popcll(live); }
+		if(live == 0ull)
+		{
+			if(STATS && lane == 0) wp[7] += 1;
+			if(uni(__hip_atomic_load(&ctl->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break; // the global queue is dry and the workgroup's last path has ended
+			__builtin_amdgcn_s_sleep(8);
+			continue;
+		}
+
+#include "traverse_trip.inc"
+	}
+
+	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------
+	if(lane == 0) { atomicAdd(&ctl->rays, wave_rays); if(wave_shaded) atomicAdd(&ctl->shaded, wave_shaded); if(wave_bad) atomicAdd(&px.stats->bad_materials, (unsigned long long)wave_bad); }
+	if(any_overflow) atomicAdd(&a.stats->overflows, 1ull);
+	__syncthreads();
+	if(threadIdx.x == 0)
+	{
+		atomicAdd(&a.stats->rays, (unsigned long long)ctl->rays);
+		if(ctl->shaded) atomicAdd(&px.stats->shaded, (unsigned long long)ctl->shaded);
+		if(blockIdx.x == 0)
+		{
+			atomicAdd(&a.stats->clock_cycles, __builtin_readcyclecounter() - clk_c0);
+			atomicAdd(&a.stats->clock_ticks, __builtin_amdgcn_s_memrealtime() - clk_r0);
+		}
+	}
+	if(STATS)
+	{
+		for(int off = 32; off > 0; off >>= 1)
+		{
+			st_nodes += __shfl_down(st_nodes, off);
+			st_tris += __shfl_down(st_tris, off);
+			st_hits += __shfl_down(st_hits, off);
+			st_maxdepth = max(st_maxdepth, (uint32_t)__shfl_down((int)st_maxdepth, off));
+			for(int i = 0; i < 8; ++i) wp[i] += __shfl_down(wp[i], off);
+		}
+		if(lane == 0)
+		{
+			for(int i = 0; i < 8; ++i) atomicAdd(&a.stats->wave_profile[i], wp[i]);
+			atomicAdd(&a.stats->nodes, st_nodes);
+			atomicAdd(&a.stats->tris, st_tris);
+			atomicAdd(&a.stats->hits, st_hits);
+			atomicMax(&a.stats->max_stack, st_maxdepth);
+		}
+	}
+}
+
+}  // namespace adypt

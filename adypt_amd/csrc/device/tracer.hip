@@ -12,6 +12,7 @@
 // There is no CPU fallback anywhere in this file: without a HIP device adypt_create fails with ADYPT_E_NO_DEVICE.
 #define ADYPT_TRACER_TU // (measure/k_trace_ablations.hpp defines its read-back entry point in this translation unit only)
 #include "traverse.hpp"
+#include "path.hpp"
 #include "ctx_access.hpp"
 #include "../../../include/adypt_hip.h"
 #include "../../../include/adypt_host.h"
@@ -117,6 +118,10 @@ struct adypt_ctx {
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0, occupancy_api = 0;
 	uint32_t refill_min = kRefillMin, chunk = kChunk, bite = kBite, endgame = kEndgame;
 	int first_fused = 1;           // ADYPT_FIRST_FUSED=0: camera rays and bounce 0 of a batch as k_gen_primary + k_shade (rounds 1-2)
+	int fused_bounces = 1;         // bounces 1 .. maxBounce-1 of a batch in ONE launch (k_path, path.hpp); ADYPT_FUSED_BOUNCES=0: k_trace + k_shade per bounce
+	int path_blocks = 0, path_lds_depth = 0; // launch geometry of k_path
+	size_t path_lds = 0;
+	uint32_t shade_min = 64;       // deposited hits a wave of k_path waits for before it shades a batch
 	int deal_chunks = 1;           // k_gen_primary deals 256-path chunks round-robin to the 8 queue segments (ADYPT_GEN_DEAL=0: one contiguous run each)
 
 	// state
@@ -254,9 +259,9 @@ void clear_counters(adypt_ctx *c, FrameCounters *first, int n, hipStream_t strea
 
 int ensure_spill(adypt_ctx *c, int stack_size)
 {
-	const int extra = stack_size - c->lds_depth;
-	if(extra <= 0) return ADYPT_OK;
-	const size_t per_pipe = (size_t)extra * (size_t)c->trace_blocks * kTraceThreads;
+	const int extra = stack_size - c->lds_depth, extra_path = c->path_blocks ? stack_size - c->path_lds_depth : 0;
+	if(extra <= 0 && extra_path <= 0) return ADYPT_OK;
+	const size_t per_pipe = std::max((size_t)std::max(extra, 0) * (size_t)c->trace_blocks, (size_t)std::max(extra_path, 0) * (size_t)c->path_blocks) * kTraceThreads;
 	const size_t need = per_pipe * kMaxPipes * sizeof(uint2);
 	if(need > c->spill_bytes)
 	{
@@ -296,7 +301,46 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	}
 	c->lds_bytes = lds;
 	c->trace_blocks = c->num_cus * per_cu;
+	// k_path (path.hpp): as many workgroups per CU as its registers allow, with the deepest LDS stack that still fits next to the path table
+	{
+		int want = 6, got = 0, depth = 1;
+		if(const char *ov = getenv("ADYPT_PATH_BLOCKS_PER_CU")) want = std::max(1, std::min(8, atoi(ov)));
+		for(; want >= 1; --want)
+		{
+			const size_t budget = (size_t)160 * 1024 / (size_t)want, fixed = path_lds_bytes(0);
+			if(budget < fixed + (size_t)(kTraceThreads / 64) * 64 * sizeof(uint2)) continue;
+			depth = (int)std::min<size_t>((size_t)std::min(stack_size, kLdsStackMax), (budget - fixed) / ((size_t)(kTraceThreads / 64) * 64 * sizeof(uint2)));
+			if(const char *ov = getenv("ADYPT_PATH_LDS_DEPTH")) depth = std::max(1, std::min(depth, atoi(ov)));
+			HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, k_path<false>, kTraceThreads, path_lds_bytes(depth)));
+			if(got >= want) break;
+		}
+		if(want < 1) return fail(c, ADYPT_E_HIP, "k_path does not fit a compute unit");
+		c->path_lds_depth = depth; c->path_lds = path_lds_bytes(depth);
+		c->path_blocks = c->num_cus * want;
+	}
 	return ensure_spill(c, stack_size);
+}
+
+// bounces b0 .. maxBounce-1 of a batched pass in one launch: the queue of parity `parity` holds the pass's rays of bounce b0
+int launch_path(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int parity, const uint32_t *count, uint32_t *cursor, const FrameArgs &f, const SceneArgs &sc,
+				const PixelArgs &px, int b0, bool stats)
+{
+	PathArgs a;
+	a.nodes = (const uint4 *)c->d_nodes; a.woop = (const float4 *)c->d_woop; a.tri_indices = (const int32_t *)c->d_tri_indices;
+	a.in_o = (const float *)c->q_o[parity] + 3 * win.offset; a.in_d = c->q_d[parity] + win.offset; a.in_col = (const float *)c->q_col[parity] + 3 * win.offset;
+	a.ray_stats = nullptr;
+	a.count = count; a.cursor = cursor;
+	a.spill = pipe.spill; a.stats = c->d_stats;
+	a.seg_cap = win.seg_cap;
+	a.stack_size = c->params.stack_size; a.lds_depth = c->path_lds_depth;
+	a.refill_min = c->refill_min; a.shade_min = c->shade_min;
+	a.b0 = b0; a.tmin = c->params.ray_tmin;
+	hipEvent_t *stop = begin_timing(c, 0, pipe.stream);
+	if(stats) hipLaunchKernelGGL(k_path<true>, dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, a, f, sc, px, 1);
+	else hipLaunchKernelGGL(k_path<false>, dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, a, f, sc, px, 0);
+	end_timing(stop, pipe.stream);
+	HIP_TRY(c, hipGetLastError());
+	return ADYPT_OK;
 }
 
 int launch_trace(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int parity, const uint32_t *count, uint32_t *cursor, int stack_size, bool stats,
@@ -641,6 +685,8 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	if(const char *ov = getenv("ADYPT_REFILL_MIN")) c->refill_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_GEN_DEAL")) c->deal_chunks = atoi(ov) != 0;
 	if(const char *ov = getenv("ADYPT_FIRST_FUSED")) c->first_fused = atoi(ov) != 0;
+	if(const char *ov = getenv("ADYPT_FUSED_BOUNCES")) c->fused_bounces = atoi(ov) != 0;
+	if(const char *ov = getenv("ADYPT_SHADE_MIN")) c->shade_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_ENDGAME")) c->endgame = (uint32_t)std::max(0, std::min(1024, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_BITE")) c->bite = (uint32_t)std::max(1, std::min(4096, atoi(ov)));
@@ -1104,7 +1150,15 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			}
 			end_timing(stop, pipe.stream);
 		}
-		for(int b = fused_first ? 1 : 0; b < max_bounce; ++b)
+		// every bounce after the first in ONE launch (k_path): the reference's for(b < uMaxBounce) inside a single dispatch
+		const bool fused_bounces = fused_first && n_pipes == 1 && c->fused_bounces && (int64_t)m * (int64_t)c->n_local_px <= kPathMaxPaths;
+		if(fused_bounces && max_bounce > 1)
+		{
+			const Pipe &pipe = c->pipes[0];
+			int r = launch_path(c, pipe, sub[0].win, 1, pipe.counters->count[1], pipe.counters->cursor[1], sub[0].f, sc, px, 1, stats);
+			if(r != ADYPT_OK) return r;
+		}
+		for(int b = fused_first ? 1 : 0; b < max_bounce && !fused_bounces; ++b)
 		{
 			const int in = b & 1;
 			for(int k = 0; k < n_pipes; ++k) // bounce by bounce over the pipes: their launches reach the GPU interleaved

@@ -88,6 +88,7 @@ __device__ __forceinline__ uint32_t fetch_rays(uint32_t seg_len_lanes, uint32_t 
 template <bool STATS, bool ANY = false>
 __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_trace(TraceArgs a) // hot variant: <= 80 VGPRs, 6 waves per SIMD
 {
+	constexpr bool kUniformTmin = false; // ray batches handed in by the caller carry a tmin per ray
 	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64], then the workgroup's ray pool (WgPool)
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
@@ -275,220 +276,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 			continue;
 		}
 
-		// No `if(active)` around the trip: a lane without a ray carries an inert state (no triangles, nothing pending, empty group,
-		// empty stack), so every step below is a no-op for it — and it stays available as a HELPER for its neighbour's second
-		// triangle (C), which needs every lane of the wave enabled when the rays are exchanged.
-		{
-			// One trip = at most one triangle PAIR (the lane's own test + its neighbour's) and at most one slab test per lane.
-			// A lane whose node produced more triangles than the trip consumes keeps its already chosen next node pending
-			// (fetched in the trip that slab-tests it): measured with adypt_get_wave_profile, an inner loop over all pairs ran
-			// 2.4 iterations per trip with 6 of 64 lanes live — 40 % of the kernel's VALU slots at 9 % utilisation.
-			// ---------------- A. choose the next node (traversal.glsl:47-66 / 245-250) unless one is pending ----------------
-			// (flat sequence of predicated steps rather than nested branches: every nesting level made the compiler copy
-			// the loop-carried ray state)
-			const bool can_pop = !pending && ng_y <= 0x00ffffffu && sp != 0;
-			if(can_pop)
-			{
-				--sp;
-				// two separate loads, each completed inside its branch: written as one select the compiler emits a single
-				// flat_load (LDS or global decided by address) that waits on both memory counters; the LDS pop is the hot one.
-				// Completing the pop here also means no older memory operation is pending when the triangle / node loads
-				// below are issued.
-				if(sp < a.lds_depth)
-				{
-					const uint2 g = my_stack[sp * 64];
-					ng_x = g.x; ng_y = g.y;
-					asm volatile("" : "+v"(ng_x), "+v"(ng_y));
-				}
-				else
-				{
-					const uint2 g = my_spill[(size_t)(sp - a.lds_depth) * total_lanes];
-					ng_x = g.x; ng_y = g.y;
-					asm volatile("" : "+v"(ng_x), "+v"(ng_y));
-				}
-			}
-			const bool choose = !pending && ng_y > 0x00ffffffu;
-			if(choose)
-			{
-				const uint32_t imask = ng_y;
-				const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng_y);
-				ng_y &= ~(1u << bit);
-				const uint32_t slot = (bit - 24u) ^ octinv;
-				node = ng_x + (uint32_t)__builtin_popcount(imask & ~(0xffffffffu << slot));
-				pending = true;
-			}
-			const bool push = choose && ng_y > 0x00ffffffu;
-			const bool push_ok = push && sp < a.stack_size;
-			if(push_ok)
-			{
-				if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);
-				else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);
-				++sp;
-				if(STATS) depth_after_push = (uint32_t)sp;
-			}
-			if(ANY) push_overflow |= push && !push_ok; // an any-hit ray may end before the visit the push belongs to
-			else overflow |= push && !push_ok;         // closest hit: the visit always follows, commit right away
-			// ---------------- B. issue every load of this trip back to back: one triangle pair, then the pending node ------
-			// The triangle PAIR of a lane is tested by TWO lanes: the lane itself takes its first triangle, its neighbour (lane ^ 1) —
-			// when that one has no triangle of its own this trip, which is the case 4 times out of 5 — takes the second one, with the
-			// owner's ray handed over by DPP quad swaps; the result comes back the same way and the owner applies it AFTER its own, with
-			// the updated hit_t: exactly the sequential order of traversal.glsl:213-243.  Per trip that is 3 triangle loads instead of 6 (the
-			// CU's vector-memory pipeline charges per instruction, not per lane: profiles/r2_l1_patterns_microbench.txt) and one Woop test
-			// instead of two.  A lane whose neighbour is busy with its own triangle keeps its second one for the next trip.
-			auto swap1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }; // quad_perm [1,0,3,2]
-			auto swap1f = [&](float v) { return __uint_as_float(swap1(__float_as_uint(v))); };
-			const bool has_tri = tg_y != 0;
-			const uint32_t tg_rest = tg_y & (tg_y - 1u);
-			const bool two = tg_rest != 0;
-			const uint32_t nb_flags = swap1((has_tri ? 1u : 0u) | (two ? 2u : 0u));
-			const bool coop = two && !(nb_flags & 1u);                  // my second triangle goes to the neighbour
-			const bool helper = !has_tri && nb_flags == 3u;             // I test the neighbour's second triangle
-			const uint32_t own_t0 = tg_x + (uint32_t)__builtin_ctz(tg_y | 0x80000000u);
-			const uint32_t own_t1 = tg_x + (uint32_t)__builtin_ctz(tg_rest | 0x80000000u);
-			const uint32_t nb_t1 = swap1(own_t1);
-			const V2 nb_od_x = v2(swap1f(od_x.x), swap1f(od_x.y)), nb_od_y = v2(swap1f(od_y.x), swap1f(od_y.y)), nb_od_z = v2(swap1f(od_z.x), swap1f(od_z.y));
-			const float nb_tmin = swap1f(tmin);
-			if(has_tri) tg_y = coop ? (tg_rest & (tg_rest - 1u)) : tg_rest; // consumed: the first triangle, and the second if it was handed over
-			const bool do_test = has_tri || helper;
-			const uint32_t tri_sel = helper ? nb_t1 : own_t0;
-			const V2 t_od_x = helper ? nb_od_x : od_x, t_od_y = helper ? nb_od_y : od_y, t_od_z = helper ? nb_od_z : od_z;
-			const float t_tmin = helper ? nb_tmin : tmin;
-			float4 wp0, wp1, wp2;
-			// registers only read under do_test / pending: "defined" by an empty asm (no instruction) instead of zero-filled —
-			// leaving them uninitialised makes the register allocator spill, zero-filling costs VALU slots every trip
-#define ADYPT_DEF4(v) asm volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))
-			ADYPT_DEF4(wp0); ADYPT_DEF4(wp1); ADYPT_DEF4(wp2);
-			if(do_test)
-			{
-				const float4 *w0 = a.woop + (size_t)tri_sel * 3;
-				wp0 = w0[0]; wp1 = w0[1]; wp2 = w0[2];
-				ADYPT_MEASURE_AFTER_TRI_LOADS(w0);
-			}
-			uint4 n0, n1, n2, n3, n4;
-			ADYPT_DEF4(n0); ADYPT_DEF4(n1); ADYPT_DEF4(n2); ADYPT_DEF4(n3); ADYPT_DEF4(n4);
-			ADYPT_MEASURE_MORE_NODE_REGS();
-			// The pending node is fetched in the trip that will slab-test it, i.e. once this trip's pair leaves no triangle behind.
-			// A lane that still has triangles after the pair used to fetch its node again every trip (an L1 hit, but the vector
-			// memory pipeline is as loaded as the vector ALU here — tools/microbench/l1_patterns.hip: a 16-byte-per-lane load costs
-			// 16 cycles per CU at best and ~0.6 cycle per distinct cache line beyond that).
-			if(pending && tg_y == 0)
-			{
-				const uint4 *np = a.nodes + (size_t)node * kNodeUint4;
-				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
-				ADYPT_MEASURE_LOAD_MORE_NODE(np);
-				ADYPT_MEASURE_AFTER_NODE_LOADS(np, lane);
-			}
-			__builtin_amdgcn_sched_barrier(0); // keep the compiler from hoisting arithmetic between the load issues
-
-			// ---------------- C. triangles of the node visited last (traversal.glsl:213-243): one Woop test per lane ----------------
-			float tt, tu, tv;
-			asm volatile("" : "=v"(tt), "=v"(tu), "=v"(tv));
-			bool geom_ok = false;
-			if(do_test)
-			{
-				if(STATS) wave_event(2);
-				// Woop test (traversal.glsl:219-242); (o·m, d·m) per row: x = dot3(origin, m.xyz), y = dot3(dir, m.xyz)
-				const V2 r0 = pk_fma(t_od_z, v2s(wp0.z), pk_fma(t_od_y, v2s(wp0.y), t_od_x * v2s(wp0.x)));
-				const V2 r1 = pk_fma(t_od_z, v2s(wp1.z), pk_fma(t_od_y, v2s(wp1.y), t_od_x * v2s(wp1.x)));
-				const V2 r2 = pk_fma(t_od_z, v2s(wp2.z), pk_fma(t_od_y, v2s(wp2.y), t_od_x * v2s(wp2.x)));
-				const float toz = wp0.w - r0.x;
-				const float tidz = 1.0f / r0.y;
-				tt = toz * tidz;
-				tu = fmaf(tt, r1.y, wp1.w + r1.x);
-				tv = fmaf(tt, r2.y, wp2.w + r2.x);
-				geom_ok = tt > t_tmin && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f;
-			}
-			if(has_tri && geom_ok && tt < hit_t) { hit_t = tt; hit_u = tu; hit_v = tv; hit_idx = (int32_t)own_t0; }
-			// the neighbour's verdict on my second triangle, applied after my first with the shortened hit_t (NaN = rejected)
-			const float nb_tt = swap1f(geom_ok ? tt : __builtin_nanf("")), nb_tu = swap1f(tu), nb_tv = swap1f(tv);
-			// any-hit: nothing is tested after the first accepted triangle (traversal.glsl:477-483)
-			const bool second = coop && !(ANY && hit_idx != -1);
-			if(second && nb_tt < hit_t) { hit_t = nb_tt; hit_u = nb_tu; hit_v = nb_tv; hit_idx = (int32_t)own_t1; }
-			if(STATS && has_tri) n_tris += second ? 2u : 1u;
-			if(ANY && has_tri && hit_idx != -1) { tg_y = 0; pending = false; }
-
-			if(tg_y != 0)
-			{
-				// more triangles of this node: next trip (the pending node is fetched in the trip that consumes the last of them)
-			}
-			else if(pending)
-			{
-				// ---------------- D. slab tests of the fetched node (traversal.glsl:69-205) ----------------
-				pending = false;
-				if(ANY) overflow |= push_overflow;
-				if(STATS) wave_event(4);
-				if(STATS) { ++n_nodes; hash = (hash * 0x01000193u) ^ node; max_depth = max(max_depth, depth_after_push); }
-				// octinv replicated into the 4 bytes: v_perm_b32 with selector 0 instead of a quarter-rate v_mul_lo_u32
-				const uint32_t octinv4 = __builtin_amdgcn_perm(0u, octinv, 0u);
-				const uint32_t head_w = n0.w;
-				const float aix = __uint_as_float((head_w & 0xffu) << 23) * idir.x;
-				const float aiy = __uint_as_float(((head_w >> 8) & 0xffu) << 23) * idir.y;
-				const float aiz = __uint_as_float(((head_w >> 16) & 0xffu) << 23) * idir.z;
-				const float aox = (__uint_as_float(n0.x) - od_x.x) * idir.x;
-				const float aoy = (__uint_as_float(n0.y) - od_y.x) * idir.y;
-				const float aoz = (__uint_as_float(n0.z) - od_z.x) * idir.z;
-				ng_x = n1.x;
-				tg_x = n1.y;
-				uint32_t hitmask = 0;
-#ifdef ADYPT_MEASURE_FP16_NODES
-				hitmask = slab_test_fp16_nodes(n1, n2, n3, n4, n5, n6, n7, nx, ny, nz, octinv4, aix, aiy, aiz, aox, aoy, aoz, tmin, hit_t);
-#else
-#pragma unroll
-				for(int g = 0; g < 2; ++g)
-				{
-					const uint32_t meta4 = g ? n1.w : n1.z;
-					const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-					// per-byte select mask for octinv (<= 7): (b << 3) - b = 7 for inner bytes, no cross-byte borrow (the compiler emits one
-					// v_mul_lo_u32 by 7: measured 1.4x the issue cost of an add on gfx950 — cheaper than two shift-ors)
-					const uint32_t inner1 = is_inner4 >> 4;
-					const uint32_t bit_index4 = (meta4 ^ (octinv4 & ((inner1 << 3) - inner1))) & 0x1f1f1f1fu;
-					const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
-					const uint32_t qlox = g ? n2.y : n2.x, qloy = g ? n2.w : n2.z, qloz = g ? n3.y : n3.x;
-					const uint32_t qhix = g ? n3.w : n3.z, qhiy = g ? n4.y : n4.x, qhiz = g ? n4.w : n4.z;
-					const uint32_t slox = nx ? qhix : qlox, shix = nx ? qlox : qhix;
-					const uint32_t sloy = ny ? qhiy : qloy, shiy = ny ? qloy : qhiy;
-					const uint32_t sloz = nz ? qhiz : qloz, shiz = nz ? qloz : qhiz;
-#pragma unroll
-					for(int j = 0; j < 4; ++j)
-					{
-						const int sh = 8 * j;
-						// (entry, exit) distance of one axis in one v_pk_fma_f32: t = fma(float(q), adj_idir, adj_org)
-						const V2 tx = pk_fma(v2((float)((slox >> sh) & 0xffu), (float)((shix >> sh) & 0xffu)), v2s(aix), v2s(aox));
-						const V2 ty = pk_fma(v2((float)((sloy >> sh) & 0xffu), (float)((shiy >> sh) & 0xffu)), v2s(aiy), v2s(aoy));
-						const V2 tz = pk_fma(v2((float)((sloz >> sh) & 0xffu), (float)((shiz >> sh) & 0xffu)), v2s(aiz), v2s(aoz));
-						const float cmin = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));   // IEEE maxNum / minNum
-						const float cmax = fminf(fminf(tx.y, ty.y), fminf(tz.y, hit_t));
-						if(cmin <= cmax) hitmask |= ((child_bits4 >> sh) & 0xffu) << ((bit_index4 >> sh) & 0xffu);
-					}
-				}
-#endif
-				ADYPT_MEASURE_AFTER_SLAB_TEST(aox, aoy, aoz, aix, aiy);
-				ng_y = (hitmask & 0xff000000u) | (head_w >> 24);
-				tg_y = hitmask & 0x00ffffffu;
-			}
-			// ---------------- E. ray finished (traversal.glsl:245-254)? ----------------
-			// Nothing left to test, to visit or to pop — checked in the SAME trip as the slab test that found no child
-			// (or the triangle pair that was the last work): a separate trip just to notice it cost one of ~13 trips per ray.
-			if(active && tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))
-			{
-				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert
-				flush = true; // hit_idx / u / v / t and `ray` stay in their registers until the refill (or the exit) writes them
-				any_overflow |= overflow;
-				if(STATS)
-				{
-					if(a.ray_stats)
-					{
-						RayStats rs;
-						rs.ref_idx = hit_idx; rs.nodes = n_nodes; rs.tris = n_tris; rs.hash = hash;
-						rs.max_depth = overflow ? 0xffffffffu : max_depth; rs.pad0 = rs.pad1 = rs.pad2 = 0;
-						a.ray_stats[ray] = rs;
-					}
-					st_nodes += n_nodes; st_tris += n_tris; st_hits += hit_idx != -1 ? 1 : 0;
-					st_maxdepth = max(st_maxdepth, max_depth);
-				}
-				active = false;
-			}
-		}
+#include "traverse_trip.inc"
 	}
 
 	if(flush) // rays finished after the queue ran dry
