@@ -13,7 +13,8 @@
 //     the slot, slot index onto the workgroup's to-shade list) and takes ready rays off the to-trace list — LDS only, a short spin lock;
 //   * whichever wave finds >= shade_min deposited hits takes 64 of them and runs one bounce of Render() for them with all 64 lanes —
 //     FetchInfo, the illum switch, accumulate on termination: exactly k_shade's work at k_shade's lane occupancy — while the other waves
-//     of the CU keep traversing and hide its gather latency; its own rays simply wait in their registers;
+//     of the CU keep traversing and hide its gather latency; its own rays wait, the ten registers of their state that cannot be recomputed
+//     from the path table parked in LDS for the round, so that the shading code has the registers (one shading wave per workgroup at a time);
 //   * a path that ends is replaced from the global queue (the bounce-1 rays k_shade_first wrote) by the shading wave itself: one device
 //     atomic per shading round, issued BEFORE the gathers for the paths that are certain to end (miss, last bounce) so that its latency is hidden;
 //   * no inter-workgroup communication of any kind, so none of the cross-XCD visibility questions of a streaming queue.
@@ -23,9 +24,13 @@
 
 namespace adypt {
 
-constexpr int kPathSlots = 384;                  // paths a workgroup holds (256 lanes + 128 ready or waiting to be shaded)
+#ifndef ADYPT_PATH_SLOTS
+#define ADYPT_PATH_SLOTS 352
+#endif
+constexpr int kPathSlots = ADYPT_PATH_SLOTS;     // paths a workgroup holds: its 256 lanes' + those ready or waiting to be shaded (tuning: tools/build_variant.sh)
+static_assert(kPathSlots >= kTraceThreads && kPathSlots <= 2 * kTraceThreads && kPathSlots % 32 == 0, "k_path: 256 <= slots <= 512");
 constexpr int kTabFields = 10;                   // path word | direction | throughput | origin (to-trace) or hit (to-shade)
-constexpr int kParkDwords = 21;                  // per-lane ray state a shading wave parks in LDS (so that the shading code has the registers)
+constexpr int kParkDwords = 10;                  // per-lane ray state a shading wave parks in LDS for the round (hit, groups, node, slot | stack pointer)
 constexpr uint32_t kPwBounceShift = 26;          // path word in the table: bits 25..0 path id, 30..26 bounce index, 31 radiance parked
 constexpr uint32_t kPwIdMask = (1u << kPwBounceShift) - 1u;
 constexpr int64_t kPathMaxPaths = (int64_t)1 << kPwBounceShift; // batches with more paths keep the launch-per-bounce pipeline
@@ -33,8 +38,8 @@ enum { T_PW = 0, T_DX, T_DY, T_DZ, T_CX, T_CY, T_CZ, T_OX, T_OY, T_OZ };
 
 struct PathCtl {                                 // workgroup control block in LDS (zeroed at start)
 	uint32_t n_shade, n_trace, live, busy;         // deposited hits, ready rays, paths alive in this workgroup, a wave is shading   <- one 16-byte peek
-	uint32_t lock, rays, shaded, init_have;
-	uint32_t pad1[8];
+	uint32_t h_shade, h_trace, rays, shaded;       // heads of the two rings (FIFO: no path waits behind younger ones)
+	uint32_t lock, init_have, pad[6];
 };
 
 struct PathArgs {
@@ -81,6 +86,9 @@ __device__ __forceinline__ void wg_unlock(PathCtl *ctl, int lane)
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+#ifndef ADYPT_PATH_PRIO
+#define ADYPT_PATH_PRIO 2
+#endif
 #ifndef ADYPT_PATH_WAVES
 #define ADYPT_PATH_WAVES 6  // waves per SIMD the register allocation is held to (6: <= 80 VGPRs, like k_trace)
 #endif
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 {
 	constexpr bool ANY = false;
 	constexpr bool kUniformTmin = true; // every ray of the pass has the pass's tmin
-	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64] | path table [kTabFields][kPathSlots] | parking [kParkDwords][64] | to-shade, to-trace lists | PathCtl
+	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64] | path table [kTabFields][kPathSlots] | parking [kParkDwords][64] | to-shade, to-trace rings | PathCtl
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
 	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
@@ -179,6 +187,22 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		if(lane == (int)__builtin_ctzll(m)) { wp[slot] += 1; wp[slot + 1] += (unsigned long long)__popcll(m); }
 	};
 
+	// The part of the ray setup (traversal.glsl:16-23) that is a function of the path slot alone: origin and direction as the table holds them
+	// while the ray is traced.  Also how a shading wave gets these registers back after a round (they are not parked).
+	auto aim = [&]() {
+		const float ox = __uint_as_float(tab[T_OX * kPathSlots + ray]), oy = __uint_as_float(tab[T_OY * kPathSlots + ray]), oz = __uint_as_float(tab[T_OZ * kPathSlots + ray]);
+		F3 dir = f3(__uint_as_float(tab[T_DX * kPathSlots + ray]), __uint_as_float(tab[T_DY * kPathSlots + ray]), __uint_as_float(tab[T_DZ * kPathSlots + ray]));
+		const float ooeps = __uint_as_float((127u - 64u) << 23);
+		dir.x = fabsf(dir.x) > ooeps ? dir.x : (dir.x >= 0 ? ooeps : -ooeps);
+		dir.y = fabsf(dir.y) > ooeps ? dir.y : (dir.y >= 0 ? ooeps : -ooeps);
+		dir.z = fabsf(dir.z) > ooeps ? dir.z : (dir.z >= 0 ? ooeps : -ooeps);
+		dir = normalize3(dir);
+		idir = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+		nx = dir.x < 0; ny = dir.y < 0; nz = dir.z < 0;
+		octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
+		od_x = v2(ox, dir.x); od_y = v2(oy, dir.y); od_z = v2(oz, dir.z);
+	};
+
 	for(;;)
 	{
 		// ---------------- start the rays of the slots the lanes have just taken (traversal.glsl:16-35) ----------------
@@ -187,17 +211,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		{
 			if(setup)
 			{
-				const float ox = __uint_as_float(tab[T_OX * kPathSlots + ray]), oy = __uint_as_float(tab[T_OY * kPathSlots + ray]), oz = __uint_as_float(tab[T_OZ * kPathSlots + ray]);
-				F3 dir = f3(__uint_as_float(tab[T_DX * kPathSlots + ray]), __uint_as_float(tab[T_DY * kPathSlots + ray]), __uint_as_float(tab[T_DZ * kPathSlots + ray]));
-				const float ooeps = __uint_as_float((127u - 64u) << 23);
-				dir.x = fabsf(dir.x) > ooeps ? dir.x : (dir.x >= 0 ? ooeps : -ooeps);
-				dir.y = fabsf(dir.y) > ooeps ? dir.y : (dir.y >= 0 ? ooeps : -ooeps);
-				dir.z = fabsf(dir.z) > ooeps ? dir.z : (dir.z >= 0 ? ooeps : -ooeps);
-				dir = normalize3(dir);
-				idir = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
-				nx = dir.x < 0; ny = dir.y < 0; nz = dir.z < 0;
-				octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
-				od_x = v2(ox, dir.x); od_y = v2(oy, dir.y); od_z = v2(oz, dir.z);
+				aim();
 				hit_t = 1e9f; hit_u = 0.0f; hit_v = 0.0f; hit_idx = -1;
 				sp = 0;
 				ng_x = 0; ng_y = 0x80000000u; tg_x = 0; tg_y = 0;
@@ -223,6 +237,9 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 			const uint32_t pk_thr = min(a.shade_min, max(1u, pk_live >> 2));
 			if(n_flush != 0u || pk_trace != 0u || (pk_shade + n_flush >= pk_thr && !pk_busy))
 			{
+				// Everything in this block runs at raised issue priority: while a wave is in here its rays do not advance, and at the fair share
+				// of a SIMD's issue slots (1 / 6) the block's few hundred instructions would keep it away from them several times longer
+				__builtin_amdgcn_s_setprio(ADYPT_PATH_PRIO);
 				// deposit, first half (no lock: the slot is this lane's until it is on the list): remap and hit (traversal.glsl:253-254)
 				if(flush)
 				{
@@ -231,28 +248,28 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					tab[T_OX * kPathSlots + ray] = (uint32_t)tri; tab[T_OY * kPathSlots + ray] = __float_as_uint(hit_u); tab[T_OZ * kPathSlots + ray] = __float_as_uint(hit_v);
 				}
 				const uint32_t fl_rank = lane_rank(fl), idle_rank = lane_rank(idle);
+				auto ring = [](uint32_t i) { return i >= (uint32_t)kPathSlots ? i - (uint32_t)kPathSlots : i; };
 				wg_lock(ctl, lane);
-				uint32_t n_s = uni(ctl->n_shade), n_t = uni(ctl->n_trace);
+				uint32_t n_s = uni(ctl->n_shade), h_s = uni(ctl->h_shade), n_t = uni(ctl->n_trace), h_t = uni(ctl->h_trace);
 				const uint32_t lv = uni(ctl->live);
-				if(flush) to_shade[n_s + fl_rank] = (uint16_t)ray;
+				if(flush) to_shade[ring(h_s + n_s + fl_rank)] = (uint16_t)ray;
 				n_s += n_flush;
 				flush = false;
 				const uint32_t thr = min(a.shade_min, max(1u, lv >> 2)); // fewer than 4 batches of paths left: smaller batches, down to single paths
-				const bool do_shade = n_s >= thr && n_s != 0u && uni(ctl->busy) == 0u; // one shading wave per workgroup at a time (one parking area)
+				const bool do_shade = n_s >= thr && n_s != 0u && uni(ctl->busy) == 0u; // one shading wave per workgroup at a time: one parking area
 				uint32_t take = 0, sslot = 0;
 				if(do_shade)
 				{
 					take = min(64u, n_s);
-					n_s -= take;
-					if((uint32_t)lane < take) sslot = to_shade[n_s + (uint32_t)lane];
-					if(lane == 0) ctl->busy = 1u;
+					if((uint32_t)lane < take) sslot = to_shade[ring(h_s + (uint32_t)lane)];
+					h_s = ring(h_s + take); n_s -= take;
+					if(lane == 0) { ctl->h_shade = h_s; ctl->busy = 1u; }
 				}
 				else
 				{
 					const uint32_t got = min(n_idle, n_t);
-					n_t -= got;
-					if(!active && idle_rank < got) { ray = to_trace[n_t + idle_rank]; setup = true; }
-					if(lane == 0) ctl->n_trace = n_t;
+					if(!active && idle_rank < got) { ray = to_trace[ring(h_t + idle_rank)]; setup = true; }
+					if(lane == 0 && got) { ctl->n_trace = n_t - got; ctl->h_trace = ring(h_t + got); }
 				}
 				if(lane == 0) ctl->n_shade = n_s;
 				wg_unlock(ctl, lane);
@@ -260,15 +277,16 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				if(do_shade)
 				{
 					// ---------------- one iteration of Render()'s loop (pathtracer.glsl:107-202) for `take` paths, one per lane ----------------
-					// The wave's own rays wait.  Their state is parked in LDS for the duration: the shading code then has the registers the
-					// traversal loop lives in (the loop itself is register-allocated exactly as in k_trace).
-					uint32_t *pk_lane = park + lane;
-					pk_lane[0 * 64] = __float_as_uint(od_x.x); pk_lane[1 * 64] = __float_as_uint(od_x.y); pk_lane[2 * 64] = __float_as_uint(od_y.x); pk_lane[3 * 64] = __float_as_uint(od_y.y);
-					pk_lane[4 * 64] = __float_as_uint(od_z.x); pk_lane[5 * 64] = __float_as_uint(od_z.y);
-					pk_lane[6 * 64] = __float_as_uint(idir.x); pk_lane[7 * 64] = __float_as_uint(idir.y); pk_lane[8 * 64] = __float_as_uint(idir.z);
-					pk_lane[9 * 64] = __float_as_uint(hit_t); pk_lane[10 * 64] = __float_as_uint(hit_u); pk_lane[11 * 64] = __float_as_uint(hit_v); pk_lane[12 * 64] = (uint32_t)hit_idx;
-					pk_lane[13 * 64] = (uint32_t)sp; pk_lane[14 * 64] = ng_x; pk_lane[15 * 64] = ng_y; pk_lane[16 * 64] = tg_x; pk_lane[17 * 64] = tg_y;
-					pk_lane[18 * 64] = node; pk_lane[19 * 64] = ray; pk_lane[20 * 64] = octinv;
+					// The wave's own rays wait.  What of their state is not a function of the path table is parked in LDS for the round: the shading
+					// code then has the registers the traversal loop lives in, and the loop itself stays register-allocated as in k_trace.
+					// (an address that belongs to this rare block is computed from a value the compiler cannot see through, or it computes it once
+					// before the persistent loop and keeps it in a register the traversal loop needs)
+					uint32_t lane_here = (uint32_t)lane;
+					asm volatile("" : "+v"(lane_here));
+					uint32_t *pk_lane = park + lane_here * 4;
+					*(uint4 *)(pk_lane + 0 * 256) = make_uint4(__float_as_uint(hit_t), __float_as_uint(hit_u), __float_as_uint(hit_v), (uint32_t)hit_idx);
+					*(uint4 *)(pk_lane + 1 * 256) = make_uint4(ng_x, ng_y, tg_x, tg_y);
+					*(uint2 *)(park + 2 * 256 + lane_here * 2) = make_uint2(node, ray | ((uint32_t)sp << 16));
 					asm volatile("" ::: "memory");
 					const bool have = (uint32_t)lane < take;
 					uint32_t pw = 0;
@@ -319,7 +337,8 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 								alive = respond(f, si, rng, b, dir, color, ret);
 							}
 						}
-						if(!alive) finish_path(f, px, pi, L, ret);
+						if(!alive) // main()'s clamp (pathtracer.glsl:224); the running mean is k_resolve's, in frame order (a k_path pass is always batched)
+							f.done[pi] = make_float4(gl_min(ret.x, f.clamp), gl_min(ret.y, f.clamp), gl_min(ret.z, f.clamp), 1.0f);
 					}
 					wave_bad += (uint32_t)__popcll(__ballot(bad_mat));
 					if(count_stats) wave_shaded += (uint32_t)__popcll(__ballot(shaded));
@@ -372,24 +391,25 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					const unsigned long long pm = __ballot(push);
 					const uint32_t n_push = (uint32_t)__popcll(pm), push_rank = lane_rank(pm);
 					const uint32_t n_lost = n_dead - (uint32_t)__popcll(__ballot(repl));
-					// the wave's own rays come back
-					asm volatile("" ::: "memory");
-					od_x = v2(__uint_as_float(pk_lane[0 * 64]), __uint_as_float(pk_lane[1 * 64])); od_y = v2(__uint_as_float(pk_lane[2 * 64]), __uint_as_float(pk_lane[3 * 64]));
-					od_z = v2(__uint_as_float(pk_lane[4 * 64]), __uint_as_float(pk_lane[5 * 64]));
-					idir = f3(__uint_as_float(pk_lane[6 * 64]), __uint_as_float(pk_lane[7 * 64]), __uint_as_float(pk_lane[8 * 64]));
-					hit_t = __uint_as_float(pk_lane[9 * 64]); hit_u = __uint_as_float(pk_lane[10 * 64]); hit_v = __uint_as_float(pk_lane[11 * 64]); hit_idx = (int32_t)pk_lane[12 * 64];
-					sp = (int)pk_lane[13 * 64]; ng_x = pk_lane[14 * 64]; ng_y = pk_lane[15 * 64]; tg_x = pk_lane[16 * 64]; tg_y = pk_lane[17 * 64];
-					node = pk_lane[18 * 64]; ray = pk_lane[19 * 64]; octinv = pk_lane[20 * 64];
+					// the wave's own rays come back: the parked registers, and origin / direction / octant from the table as at the ray's start
+					{
+						const uint4 p0 = *(const uint4 *)(pk_lane + 0 * 256), p1 = *(const uint4 *)(pk_lane + 1 * 256);
+						const uint2 p2 = *(const uint2 *)(park + 2 * 256 + lane_here * 2);
+						hit_t = __uint_as_float(p0.x); hit_u = __uint_as_float(p0.y); hit_v = __uint_as_float(p0.z); hit_idx = (int32_t)p0.w;
+						ng_x = p1.x; ng_y = p1.y; tg_x = p1.z; tg_y = p1.w;
+						node = p2.x; ray = p2.y & 0xffffu; sp = (int)(p2.y >> 16);
+						aim();
+					}
 					wg_lock(ctl, lane);
-					n_t = uni(ctl->n_trace);
-					if(push) to_trace[n_t + push_rank] = (uint16_t)sslot;
+					n_t = uni(ctl->n_trace); h_t = uni(ctl->h_trace);
+					if(push) to_trace[ring(h_t + n_t + push_rank)] = (uint16_t)sslot;
 					n_t += n_push;
-					const uint32_t got = min(n_idle, n_t); // and the wave's own idle lanes take the first of them
-					n_t -= got;
-					if(!active && idle_rank < got) { ray = to_trace[n_t + idle_rank]; setup = true; }
-					if(lane == 0) { ctl->n_trace = n_t; if(n_lost) ctl->live = ctl->live - n_lost; ctl->busy = 0u; }
+					const uint32_t got = min(n_idle, n_t); // and the wave's own idle lanes take the oldest ready rays
+					if(!active && idle_rank < got) { ray = to_trace[ring(h_t + idle_rank)]; setup = true; }
+					if(lane == 0) { ctl->n_trace = n_t - got; ctl->h_trace = ring(h_t + got); if(n_lost) ctl->live = ctl->live - n_lost; ctl->busy = 0u; }
 					wg_unlock(ctl, lane);
 				}
+				__builtin_amdgcn_s_setprio(0);
 				if(__ballot(setup)) continue;
 			}
 		}

@@ -305,11 +305,13 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	{
 		int want = 6, got = 0, depth = 1;
 		if(const char *ov = getenv("ADYPT_PATH_BLOCKS_PER_CU")) want = std::max(1, std::min(8, atoi(ov)));
-		for(; want >= 1; --want)
+		for(; want >= 1 && got < want; --want)
 		{
-			const size_t budget = (size_t)160 * 1024 / (size_t)want, fixed = path_lds_bytes(0);
-			if(budget < fixed + (size_t)(kTraceThreads / 64) * 64 * sizeof(uint2)) continue;
-			depth = (int)std::min<size_t>((size_t)std::min(stack_size, kLdsStackMax), (budget - fixed) / ((size_t)(kTraceThreads / 64) * 64 * sizeof(uint2)));
+			// LDS is handed out in granules; the occupancy query does not know: measured, it answers 6 for 26944 bytes per workgroup, of which a
+			// compute unit then runs 5 at a time (the sixth of every six waits for a slot: -5 %).  So the budget is whole KiB of 160 / want.
+			const size_t budget = ((size_t)160 / (size_t)want) * 1024, fixed = path_lds_bytes(0), per_entry = (size_t)(kTraceThreads / 64) * 64 * sizeof(uint2);
+			if(budget < fixed + per_entry) continue;
+			depth = (int)std::min<size_t>((size_t)std::min(stack_size, kLdsStackMax), (budget - fixed) / per_entry);
 			if(const char *ov = getenv("ADYPT_PATH_LDS_DEPTH")) depth = std::max(1, std::min(depth, atoi(ov)));
 			HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, k_path<false>, kTraceThreads, path_lds_bytes(depth)));
 			if(got >= want) break;
@@ -317,6 +319,7 @@ int configure_trace(adypt_ctx *c, int stack_size)
 		if(want < 1) return fail(c, ADYPT_E_HIP, "k_path does not fit a compute unit");
 		c->path_lds_depth = depth; c->path_lds = path_lds_bytes(depth);
 		c->path_blocks = c->num_cus * want;
+		if(getenv("ADYPT_PATH_VERBOSE")) fprintf(stderr, "[adypt] k_path: %d workgroups per CU, %d path slots each, LDS stack depth %d, %zu bytes of LDS\n", want, kPathSlots, depth, c->path_lds);
 	}
 	return ensure_spill(c, stack_size);
 }

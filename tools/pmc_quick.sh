@@ -12,4 +12,4 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
 done
 python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
 find $OUT -name "*counter_collection.csv" -delete
-grep -A14 "^k_trace<false" $OUT/pmc_summary.txt
+cp $OUT/pmc_summary.txt ${PMC_QUICK_COPY:-$OUT/pmc_summary_copy.txt}; grep -A14 "^k_trace<false\|^k_path<false\|^k_shade(" $OUT/pmc_summary.txt
