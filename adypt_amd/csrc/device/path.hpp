@@ -17,6 +17,9 @@
 //     from the path table parked in LDS for the round, so that the shading code has the registers (one shading wave per workgroup at a time);
 //   * a path that ends is replaced from the global queue (the bounce-1 rays k_shade_first wrote) by the shading wave itself: one device
 //     atomic per shading round, issued BEFORE the gathers for the paths that are certain to end (miss, last bounce) so that its latency is hidden;
+//   * the hit's triangle record is looked up by REFERENCE index (the traversal's own index: SceneArgs::triangles here is the per-reference copy
+//     of the records, made once at upload), so the uTriIndices remap (traversal.glsl:253-254) — a dependent load in front of every deposit —
+//     disappears from this kernel; the triangle id itself is never an output of these bounces;
 //   * no inter-workgroup communication of any kind, so none of the cross-XCD visibility questions of a streaming queue.
 // The kernel ends when the global queue is dry and every workgroup has finished the paths it holds.
 #pragma once
@@ -45,7 +48,6 @@ struct PathCtl {                                 // workgroup control block in L
 struct PathArgs {
 	const uint4 *nodes;
 	const float4 *woop;
-	const int32_t *tri_indices;
 	const float *in_o; const float4 *in_d; const float *in_col; // the batch's ray queue as k_shade_first leaves it (12 / 16 / 12 bytes per path)
 	RayStats *ray_stats;           // always null (traverse_trip.inc's per-ray record belongs to adypt_trace_rays)
 	const uint32_t *count;         // paths per queue segment: count[s * kCursorStride]
@@ -240,13 +242,8 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				// Everything in this block runs at raised issue priority: while a wave is in here its rays do not advance, and at the fair share
 				// of a SIMD's issue slots (1 / 6) the block's few hundred instructions would keep it away from them several times longer
 				__builtin_amdgcn_s_setprio(ADYPT_PATH_PRIO);
-				// deposit, first half (no lock: the slot is this lane's until it is on the list): remap and hit (traversal.glsl:253-254)
-				if(flush)
-				{
-					int32_t tri = -1;
-					if(hit_idx != -1) tri = a.tri_indices[hit_idx];
-					tab[T_OX * kPathSlots + ray] = (uint32_t)tri; tab[T_OY * kPathSlots + ray] = __float_as_uint(hit_u); tab[T_OZ * kPathSlots + ray] = __float_as_uint(hit_v);
-				}
+				// deposit, first half (no lock: the slot is this lane's until it is on the list): the hit, by reference index
+				if(flush) { tab[T_OX * kPathSlots + ray] = (uint32_t)hit_idx; tab[T_OY * kPathSlots + ray] = __float_as_uint(hit_u); tab[T_OZ * kPathSlots + ray] = __float_as_uint(hit_v); }
 				const uint32_t fl_rank = lane_rank(fl), idle_rank = lane_rank(idle);
 				auto ring = [](uint32_t i) { return i >= (uint32_t)kPathSlots ? i - (uint32_t)kPathSlots : i; };
 				wg_lock(ctl, lane);

@@ -49,6 +49,14 @@ struct EventPair { hipEvent_t a, b; int kind; };
 // the runtime's dependency tracking cannot see) — round 3: cache images and counters read before / cleared after their time.
 __global__ void k_clear_counters(uint4 *p, uint32_t n16) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if(i < n16) p[i] = make_uint4(0, 0, 0, 0); }
 
+// out[r] = the 128-byte device record of triangle tri_indices[r]: the uTriIndices remap (traversal.glsl:253-254) applied to the data once, so that k_path
+// looks a hit's triangle up by the traversal's own reference index.  One thread per 16 bytes.
+__global__ void k_expand_references(const float4 *triangles, const int32_t *tri_indices, size_t n_refs, float4 *out)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n_refs * kTriFloat4) out[i] = triangles[(size_t)tri_indices[i / kTriFloat4] * kTriFloat4 + i % kTriFloat4];
+}
+
 // One sub-batch chain of a pipelined batch.  Pipe 0 runs on the context's stream.
 struct Pipe {
 	hipStream_t stream = nullptr;
@@ -70,6 +78,7 @@ struct adypt_ctx {
 	// scene (immutable after create)
 	void *d_nodes = nullptr, *d_woop = nullptr, *d_tri_indices = nullptr, *d_triangles = nullptr, *d_materials = nullptr, *d_tri_class = nullptr;
 	void *d_texels = nullptr, *d_local_blocks = nullptr;
+	void *d_ref_triangles = nullptr;          // k_path: the triangle records once per REFERENCE (uTriIndices order), made on the device at the first fused batch
 	void *d_all_blocks = nullptr;             // adypt_assemble_radiance: block lists of all ranks
 	std::vector<int64_t> all_blocks_offset;
 	int64_t n_nodes = 0, n_refs = 0, n_tris = 0, n_mats = 0;
@@ -329,7 +338,7 @@ int launch_path(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int pari
 				const PixelArgs &px, int b0, bool stats)
 {
 	PathArgs a;
-	a.nodes = (const uint4 *)c->d_nodes; a.woop = (const float4 *)c->d_woop; a.tri_indices = (const int32_t *)c->d_tri_indices;
+	a.nodes = (const uint4 *)c->d_nodes; a.woop = (const float4 *)c->d_woop;
 	a.in_o = (const float *)c->q_o[parity] + 3 * win.offset; a.in_d = c->q_d[parity] + win.offset; a.in_col = (const float *)c->q_col[parity] + 3 * win.offset;
 	a.ray_stats = nullptr;
 	a.count = count; a.cursor = cursor;
@@ -832,7 +841,7 @@ void adypt_destroy(adypt_ctx *c)
 	c->comm = nullptr;
 	for(EventPair &p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_tri_class, c->d_texels, c->d_local_blocks,
+	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_tri_class, c->d_texels, c->d_ref_triangles, c->d_local_blocks,
 					c->d_accum, c->d_cache, c->d_cache_next, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
 					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol, c->d_display};
 	for(void *b : bufs) if(b) (void)hipFree(b);
@@ -1158,7 +1167,16 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		if(fused_bounces && max_bounce > 1)
 		{
 			const Pipe &pipe = c->pipes[0];
-			int r = launch_path(c, pipe, sub[0].win, 1, pipe.counters->count[1], pipe.counters->cursor[1], sub[0].f, sc, px, 1, stats);
+			if(!c->d_ref_triangles) // once per context: the triangle records in reference order (path.hpp)
+			{
+				const size_t n16 = (size_t)c->n_refs * kTriFloat4;
+				HIP_TRY(c, hipMalloc(&c->d_ref_triangles, std::max<size_t>(n16, 1) * sizeof(float4)));
+				if(n16) hipLaunchKernelGGL(k_expand_references, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, (const float4 *)c->d_triangles, (const int32_t *)c->d_tri_indices, (size_t)c->n_refs, (float4 *)c->d_ref_triangles);
+				HIP_TRY(c, hipGetLastError());
+			}
+			SceneArgs sc_ref = sc;
+			sc_ref.triangles = (const float4 *)c->d_ref_triangles;
+			int r = launch_path(c, pipe, sub[0].win, 1, pipe.counters->count[1], pipe.counters->cursor[1], sub[0].f, sc_ref, px, 1, stats);
 			if(r != ADYPT_OK) return r;
 		}
 		for(int b = fused_first ? 1 : 0; b < max_bounce && !fused_bounces; ++b)

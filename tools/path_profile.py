@@ -14,9 +14,10 @@ s = p.GetStats(); w = list(p.GetWaveProfile().values())
 total = w[0]
 hi = lambda v: v >> 32
 lo = lambda v: v & 0xffffffff
-print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("ADYPT_")}, "ms_per_frame": round(dt * 1e3 / fr, 4), "k_path_ms": round(s["trace_ms"], 3),
-                  "wave_time_shares": {"exchange_incl_shading": round(w[1] / total, 4), "shading": round(w[2] / total, 4), "idle_sleep": round(w[3] / total, 4), "lock_wait": round(w[4] / total, 4),
-                                       "trips_and_rest": round(1 - (w[1] + w[3]) / total, 4)},
-                  "shading_rounds": hi(w[5]), "paths_per_round": round(lo(w[5]) / max(1, hi(w[5])), 2), "exchanges": hi(w[6]), "hungry_trips": lo(w[6]), "trips": hi(w[7]),
-                  "lanes_per_trip": round(lo(w[7]) * 64 / max(1, hi(w[7])), 2),
+print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("ADYPT_") and k != "ADYPT_RCCL_LIB"}, "ms_per_frame": round(dt * 1e3 / fr, 4), "k_path_ms": round(s["trace_ms"], 3),
+                  "wave_time_shares": {"exchange_incl_shading": round(w[1] / total, 4), "shading_rounds": round(w[2] / total, 4), "idle_sleep": round(w[3] / total, 4),
+                                       "lock_wait": round(lo(w[6]) * 256 / total, 4), "trips_and_rest": round(1 - (w[1] + w[3]) / total, 4)},
+                  "shading_rounds": hi(w[5]), "paths_per_round": round(lo(w[5]) / max(1, hi(w[5])), 2), "exchanges": hi(w[6]), "trips": hi(w[7]),
+                  "lanes_per_trip": round(lo(w[7]) * 64 / max(1, hi(w[7])), 2), "wanted_to_shade_but_busy": w[4] >> 40,
+                  "avg_to_shade_backlog_at_exchange": round((w[4] & ((1 << 40) - 1)) / max(1, hi(w[6])), 1),
                   "avg_round_cycles": round(w[2] / max(1, hi(w[5]))), "avg_exchange_cycles_excl_shading": round((w[1] - w[2]) / max(1, hi(w[6]))), "rays": int(s["rays"])}))
