@@ -49,7 +49,9 @@ class Hit(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("hits", C.c_uint64),
                 ("shaded", C.c_uint64), ("stack_overflows", C.c_uint64), ("bad_materials", C.c_uint64),
-                ("max_stack", C.c_uint32), ("trace_launches", C.c_uint32), ("trace_ms", C.c_double), ("shade_ms", C.c_double)]
+                ("max_stack", C.c_uint32), ("trace_launches", C.c_uint32), ("trace_ms", C.c_double), ("shade_ms", C.c_double),
+                ("path_ms", C.c_double), ("path_launches", C.c_uint32), ("reserved", C.c_uint32), ("path_rays", C.c_uint64),
+                ("path_nodes", C.c_uint64), ("path_tris", C.c_uint64), ("path_hits", C.c_uint64), ("path_shaded", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -131,6 +133,10 @@ _SIGS = {
     "adypt_multi_read_radiance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "adypt_multi_gather_radiance": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "adypt_multi_comm_init": (C.c_int, [C.c_void_p]),
+    "adypt_multi_comm_ranks": (C.c_int, [C.c_void_p]),
+    "adypt_comm_ranks": (C.c_int, [C.c_void_p]),
+    "adypt_set_fused_bounces": (C.c_int, [C.c_void_p, C.c_int]),
+    "adypt_get_fused_bounces": (C.c_int, [C.c_void_p]),
     "adypt_comm_unique_id": (C.c_int, [C.c_char_p]),
     "adypt_comm_init": (C.c_int, [C.c_void_p, C.c_char_p]),
     "adypt_comm_gather_radiance": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -213,7 +219,7 @@ for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export what the headers declare
     _fn.restype = _res
     _fn.argtypes = _args
-if lib.adypt_abi_version() != 2:
+if lib.adypt_abi_version() != 3:
     raise ImportError("adypt_amd: ABI version mismatch")
 
 

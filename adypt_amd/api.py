@@ -382,6 +382,17 @@ class HipPathTracer:
     def GetPipeline(self) -> int:
         return N.lib.adypt_get_pipeline(self._ctx)
 
+    def SetFusedBounces(self, enabled: bool) -> None:
+        """Every bounce after the first of a batch in one launch (k_path); default on.  Images are bit-identical either way."""
+        N.check(N.lib.adypt_set_fused_bounces(self._ctx, 1 if enabled else 0), self._ctx)
+
+    def GetFusedBounces(self) -> bool:
+        """Whether the last batch of frames ran its bounces in one launch."""
+        return N.lib.adypt_get_fused_bounces(self._ctx) == 1
+
+    def CommRanks(self) -> int:
+        return N.lib.adypt_comm_ranks(self._ctx)
+
     def SetLookahead(self, enabled: bool) -> None:
         """One Trace(true) per call (Instance::Update) at batched throughput: see adypt_set_lookahead."""
         N.check(N.lib.adypt_set_lookahead(self._ctx, 1 if enabled else 0), self._ctx)
@@ -546,6 +557,33 @@ class MultiPathTracer:
     def CommInit(self) -> None:
         self._check(N.lib.adypt_multi_comm_init(self._m))
 
+    def CommRanks(self) -> int:
+        """Ranks of the communicator as RCCL reports them (ncclCommCount); 0 = none (one device, the shared-device test hook)."""
+        return N.lib.adypt_multi_comm_ranks(self._m)
+
+    def _contexts(self):
+        return [N.lib.adypt_multi_context(self._m, i) for i in range(self.DeviceCount())]
+
+    def GetFramesInFlight(self) -> int:
+        return N.lib.adypt_get_frames_in_flight(self._contexts()[0])
+
+    def GetFusedBounces(self) -> bool:
+        return N.lib.adypt_get_fused_bounces(self._contexts()[0]) == 1
+
+    def ResetStats(self) -> None:
+        for c in self._contexts():
+            N.check(N.lib.adypt_reset_stats(c), c)
+
+    def DeviceSynchronize(self) -> None:
+        for c in self._contexts():
+            N.check(N.lib.adypt_device_synchronize(c), c)
+
+    def GetShaderClockGHz(self) -> float:
+        out = (C.c_uint64 * 2)()
+        c = self._contexts()[0]
+        N.check(N.lib.adypt_get_shader_clock(c, out), c)
+        return float(out[0]) / float(out[1]) * 0.1 if out[1] else 0.0
+
     def Trace(self, enable_pt: bool, n_spp: int = 1) -> None:
         if enable_pt:
             self.m_viewer_type = ViewerTypes.kPTRadiance
@@ -625,13 +663,16 @@ class Instance:
         self.m_valid = False
 
     def InitializeFromFile(self, filename: str, shift_seed: int = 12345, device: int = 0, tile_rank: int = 0,
-                           tile_nranks: int = 1) -> bool:
+                           tile_nranks: int = 1, devices: Optional[Sequence[int]] = None) -> bool:
         self.m_filename = filename
         if not self.m_config.LoadFromFile(filename):
             return False
-        return self.Initialize(shift_seed, device, tile_rank, tile_nranks)
+        return self.Initialize(shift_seed, device, tile_rank, tile_nranks, devices)
 
-    def Initialize(self, shift_seed: int = 12345, device: int = 0, tile_rank: int = 0, tile_nranks: int = 1) -> bool:
+    def Initialize(self, shift_seed: int = 12345, device: int = 0, tile_rank: int = 0, tile_nranks: int = 1,
+                   devices: Optional[Sequence[int]] = None) -> bool:
+        """devices: a list of HIP device ordinals -> ONE process drives all of them through adypt_create_multi (tile rank i on
+        devices[i]; m_path_tracer is then a MultiPathTracer), as integration/HipPathTracer.hpp does for the reference's Instance."""
         cfg = self.m_config
         self.scene = Scene()
         if not self.scene.LoadFromFile(cfg.m_obj_filename):
@@ -643,7 +684,11 @@ class Instance:
             if not self.bvh.SaveToFile(cfg.m_bvh_filename, bp):
                 return False
         self.m_hipscene.Initialize(self.scene, self.bvh)
-        self.m_path_tracer.Initialize(cfg.pt_params(shift_seed), self.m_hipscene, cfg.m_width, cfg.m_height, device, tile_rank, tile_nranks)
+        if devices is not None:
+            self.m_path_tracer = MultiPathTracer()
+            self.m_path_tracer.Initialize(cfg.pt_params(shift_seed), self.m_hipscene, cfg.m_width, cfg.m_height, list(devices))
+        else:
+            self.m_path_tracer.Initialize(cfg.pt_params(shift_seed), self.m_hipscene, cfg.m_width, cfg.m_height, device, tile_rank, tile_nranks)
         self.m_camera.Initialize(cfg, cfg.m_width, cfg.m_height)
         ip, iv = self.m_camera.matrices()
         self.m_path_tracer.SetCamera(ip, iv, self.m_camera.position)

@@ -34,6 +34,7 @@ struct RcclApi {
 	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
 	ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr; // optional
 	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -80,7 +81,7 @@ RcclApi *rccl(std::string *err)
 #define LOAD(field, sym) a.field = (decltype(a.field))dlsym(h, sym)
 		LOAD(GetUniqueId, "ncclGetUniqueId"); LOAD(CommInitRank, "ncclCommInitRank"); LOAD(CommInitAll, "ncclCommInitAll");
 		LOAD(CommDestroy, "ncclCommDestroy"); LOAD(Send, "ncclSend"); LOAD(Recv, "ncclRecv"); LOAD(AllReduce, "ncclAllReduce");
-		LOAD(GroupStart, "ncclGroupStart"); LOAD(GroupEnd, "ncclGroupEnd"); LOAD(GetErrorString, "ncclGetErrorString");
+		LOAD(GroupStart, "ncclGroupStart"); LOAD(GroupEnd, "ncclGroupEnd"); LOAD(GetErrorString, "ncclGetErrorString"); LOAD(CommCount, "ncclCommCount");
 #undef LOAD
 		if(a.GetUniqueId && a.CommInitRank && a.CommInitAll && a.CommDestroy && a.Send && a.Recv && a.AllReduce && a.GroupStart && a.GroupEnd && a.GetErrorString)
 		{
@@ -303,8 +304,10 @@ int adypt_multi_get_stats(adypt_multi *m, adypt_stats *out)
 		// counts add up over the devices; the devices run concurrently, so times are the slowest device's
 		out->rays += s.rays; out->nodes_visited += s.nodes_visited; out->tris_tested += s.tris_tested; out->hits += s.hits; out->shaded += s.shaded;
 		out->stack_overflows += s.stack_overflows; out->bad_materials += s.bad_materials;
+		out->path_rays += s.path_rays; out->path_nodes += s.path_nodes; out->path_tris += s.path_tris; out->path_hits += s.path_hits; out->path_shaded += s.path_shaded;
 		out->max_stack = std::max(out->max_stack, s.max_stack); out->trace_launches = std::max(out->trace_launches, s.trace_launches);
 		out->trace_ms = std::max(out->trace_ms, s.trace_ms); out->shade_ms = std::max(out->shade_ms, s.shade_ms);
+		out->path_ms = std::max(out->path_ms, s.path_ms); out->path_launches = std::max(out->path_launches, s.path_launches);
 	}
 	return ADYPT_OK;
 }
@@ -330,6 +333,18 @@ int adypt_multi_comm_init(adypt_multi *m)
 	if(m->shared_device) return mfail(m, ADYPT_E_STATE, "adypt_multi_comm_init: no RCCL communicator in the shared-device test mode (RCCL needs distinct devices)");
 	return multi_comm_init(m);
 }
+
+// ranks as the communicator itself reports them (what a scaling run prints next to n_gpus)
+static int comm_ranks_of(adypt_ctx *ctx)
+{
+	Comm *k = comm_of(ctx);
+	if(!k || !k->comm) return 0;
+	int n = 0;
+	if(k->api && k->api->CommCount && k->api->CommCount(k->comm, &n) == ncclSuccess) return n;
+	return k->nranks; // (a transport without ncclCommCount: the size the communicator was created with)
+}
+int adypt_multi_comm_ranks(adypt_multi *m) { return (m && !m->ctx.empty()) ? comm_ranks_of(m->ctx[0]) : ADYPT_E_INVALID; }
+int adypt_comm_ranks(adypt_ctx *ctx) { return ctx ? comm_ranks_of(ctx) : ADYPT_E_INVALID; }
 
 int adypt_multi_gather_radiance(adypt_multi *m, void **rgb_device)
 {

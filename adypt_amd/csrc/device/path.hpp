@@ -211,6 +211,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		const unsigned long long starting = __ballot(setup);
 		if(starting)
 		{
+			asm volatile("; ADYPT_MARK setup_begin"); // (comments in the assembly: tools/instruction_mix.py weights the blocks of the loop by how often they run)
 			if(setup)
 			{
 				aim();
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				setup = false;
 			}
 			wave_rays += (uint32_t)__popcll(starting);
+			asm volatile("; ADYPT_MARK setup_end");
 		}
 
 		// ---------------- exchange with the workgroup: deposit finished rays, shade a batch, take ready rays ----------------
@@ -242,6 +244,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				// Everything in this block runs at raised issue priority: while a wave is in here its rays do not advance, and at the fair share
 				// of a SIMD's issue slots (1 / 6) the block's few hundred instructions would keep it away from them several times longer
 				__builtin_amdgcn_s_setprio(ADYPT_PATH_PRIO);
+				asm volatile("; ADYPT_MARK exchange_begin");
 				// deposit, first half (no lock: the slot is this lane's until it is on the list): the hit, by reference index
 				if(flush) { tab[T_OX * kPathSlots + ray] = (uint32_t)hit_idx; tab[T_OY * kPathSlots + ray] = __float_as_uint(hit_u); tab[T_OZ * kPathSlots + ray] = __float_as_uint(hit_v); }
 				const uint32_t fl_rank = lane_rank(fl), idle_rank = lane_rank(idle);
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 
 				if(do_shade)
 				{
+					asm volatile("; ADYPT_MARK shade_begin");
 					// ---------------- one iteration of Render()'s loop (pathtracer.glsl:107-202) for `take` paths, one per lane ----------------
 					// The wave's own rays wait.  What of their state is not a function of the path table is parked in LDS for the round: the shading
 					// code then has the registers the traversal loop lives in, and the loop itself stays register-allocated as in k_trace.
@@ -405,7 +409,9 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					if(!active && idle_rank < got) { ray = to_trace[ring(h_t + idle_rank)]; setup = true; }
 					if(lane == 0) { ctl->n_trace = n_t - got; ctl->h_trace = ring(h_t + got); if(n_lost) ctl->live = ctl->live - n_lost; ctl->busy = 0u; }
 					wg_unlock(ctl, lane);
+					asm volatile("; ADYPT_MARK shade_end");
 				}
+				asm volatile("; ADYPT_MARK exchange_end");
 				__builtin_amdgcn_s_setprio(0);
 				if(__ballot(setup)) continue;
 			}
@@ -430,7 +436,8 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	if(threadIdx.x == 0)
 	{
 		atomicAdd(&a.stats->rays, (unsigned long long)ctl->rays);
-		if(ctl->shaded) atomicAdd(&px.stats->shaded, (unsigned long long)ctl->shaded);
+		atomicAdd(&a.stats->path_rays, (unsigned long long)ctl->rays);
+		if(ctl->shaded) { atomicAdd(&px.stats->shaded, (unsigned long long)ctl->shaded); atomicAdd(&px.stats->path_shaded, (unsigned long long)ctl->shaded); }
 		if(blockIdx.x == 0)
 		{
 			atomicAdd(&a.stats->clock_cycles, __builtin_readcyclecounter() - clk_c0);
@@ -450,9 +457,9 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		if(lane == 0)
 		{
 			for(int i = 0; i < 8; ++i) atomicAdd(&a.stats->wave_profile[i], wp[i]);
-			atomicAdd(&a.stats->nodes, st_nodes);
-			atomicAdd(&a.stats->tris, st_tris);
-			atomicAdd(&a.stats->hits, st_hits);
+			atomicAdd(&a.stats->nodes, st_nodes); atomicAdd(&a.stats->path_nodes, st_nodes);
+			atomicAdd(&a.stats->tris, st_tris); atomicAdd(&a.stats->path_tris, st_tris);
+			atomicAdd(&a.stats->hits, st_hits); atomicAdd(&a.stats->path_hits, st_hits);
 			atomicMax(&a.stats->max_stack, st_maxdepth);
 		}
 	}

@@ -46,6 +46,7 @@ struct DeviceStats {                           // accumulated until adypt_reset_
 	uint32_t max_stack, pad;
 	unsigned long long wave_profile[8];          // adypt_get_wave_profile (instrumented traversal only)
 	unsigned long long clock_cycles, clock_ticks; // adypt_get_shader_clock: shader cycles / 100 MHz ticks of workgroup 0 over the traversal launches
+	unsigned long long path_rays, path_nodes, path_tris, path_hits, path_shaded; // k_path's share of rays / nodes / tris / hits / shaded
 };
 
 struct RayStats { int32_t ref_idx; uint32_t nodes, tris, hash, max_depth, pad0, pad1, pad2; }; // 32 B, STATS variant
@@ -344,15 +345,6 @@ __device__ inline F3 sample_texture(const SceneArgs &sc, int4 d, float s, float 
 	return r;
 }
 
-// Measurement hook, identity in the product.  -DADYPT_MEASUREMENT_BUILD -DADYPT_ABLATE_SHADE_TRI_L2 folds k_shade's triangle gather onto
-// the first 16384 records (2 MB: resident in every XCD's L2) — wrong images, but the kernel's time then says what the gathers' misses cost
-// (profiles/r3_ablations_k_trace.txt item 10).
-#if defined(ADYPT_MEASUREMENT_BUILD) && defined(ADYPT_ABLATE_SHADE_TRI_L2)
-#define ADYPT_MEASURE_SHADE_GATHER_INDEX(i) ((i) & 16383)
-#else
-#define ADYPT_MEASURE_SHADE_GATHER_INDEX(i) (i)
-#endif
-
 // the always-needed 80 bytes of a triangle: positions, normals, material id
 struct TriCore { float v[20]; };
 __device__ __forceinline__ TriCore load_tri_core(const SceneArgs &sc, int tri_idx)
@@ -424,7 +416,7 @@ struct SurfaceInfo { F3 origin, normal, diffuse, specular, emission; int illum0;
 __device__ __forceinline__ SurfaceInfo fetch_info(const FrameArgs &f, const SceneArgs &sc, int tri_idx, float tu, float tv)
 {
 	SurfaceInfo s;
-	const TriCore tc = load_tri_core(sc, ADYPT_MEASURE_SHADE_GATHER_INDEX(tri_idx));
+	const TriCore tc = load_tri_core(sc, tri_idx);
 	const float *tri = tc.v;
 	const int matid = __float_as_int(tri[18]);
 	// the hit's geometry before the material is looked at: all five loads of the record are then in flight together (with the

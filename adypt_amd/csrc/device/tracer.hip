@@ -10,7 +10,6 @@
 // (one dispatch runs the whole for(b < uMaxBounce) loop, shaders/pathtracer.glsl:107); results do not depend on any of this:
 // per-path work is independent of queue order and k_resolve applies the finished samples in frame order.
 // There is no CPU fallback anywhere in this file: without a HIP device adypt_create fails with ADYPT_E_NO_DEVICE.
-#define ADYPT_TRACER_TU // (measure/k_trace_ablations.hpp defines its read-back entry point in this translation unit only)
 #include "traverse.hpp"
 #include "path.hpp"
 #include "ctx_access.hpp"
@@ -153,8 +152,9 @@ struct adypt_ctx {
 
 	std::vector<EventPair> events;
 	std::vector<EventPair> free_events;
-	double trace_ms = 0, shade_ms = 0;
-	uint32_t trace_launches = 0;
+	double trace_ms = 0, shade_ms = 0, path_ms = 0;
+	uint32_t trace_launches = 0, path_launches = 0;
+	bool last_batch_fused = false;
 };
 
 namespace {
@@ -253,7 +253,11 @@ void harvest_events(adypt_ctx *c)
 	for(EventPair &p : c->events)
 	{
 		float ms = 0.0f;
-		if(hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { if(p.kind == 0) { c->trace_ms += ms; ++c->trace_launches; } else c->shade_ms += ms; }
+		if(hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
+		{
+			if(p.kind == 0 || p.kind == 2) { c->trace_ms += ms; ++c->trace_launches; } else c->shade_ms += ms;
+			if(p.kind == 2) { c->path_ms += ms; ++c->path_launches; }
+		}
 		c->free_events.push_back(p);
 	}
 	c->events.clear();
@@ -347,7 +351,7 @@ int launch_path(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int pari
 	a.stack_size = c->params.stack_size; a.lds_depth = c->path_lds_depth;
 	a.refill_min = c->refill_min; a.shade_min = c->shade_min;
 	a.b0 = b0; a.tmin = c->params.ray_tmin;
-	hipEvent_t *stop = begin_timing(c, 0, pipe.stream);
+	hipEvent_t *stop = begin_timing(c, 2, pipe.stream);
 	if(stats) hipLaunchKernelGGL(k_path<true>, dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, a, f, sc, px, 1);
 	else hipLaunchKernelGGL(k_path<false>, dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, a, f, sc, px, 0);
 	end_timing(stop, pipe.stream);
@@ -710,14 +714,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	c->n_local_blocks = (int)c->local_blocks.size();
 	c->n_local_px = c->n_local_blocks * kBlockPixels;
 
-#ifdef ADYPT_MEASURE_FP16_NODES // measurement-only build (csrc/measure/k_trace_ablations.hpp): 128-byte nodes with binary16 bounds
-	{
-		const std::vector<uint8_t> wide = adypt::nodes_as_fp16((const uint8_t *)d->nodes, (size_t)d->n_nodes);
-		TRY_CREATE(upload(c, &c->d_nodes, wide.data(), wide.size()));
-	}
-#else
 	TRY_CREATE(upload(c, &c->d_nodes, (const uint8_t *)d->nodes, (size_t)d->n_nodes * 80));
-#endif
 	TRY_CREATE(upload(c, &c->d_tri_indices, d->tri_indices, (size_t)d->n_refs));
 	{
 		std::vector<float> woop;
@@ -965,6 +962,15 @@ int adypt_set_pipeline(adypt_ctx *c, int n_pipes)
 
 int adypt_get_pipeline(const adypt_ctx *c) { return c ? c->pipeline : ADYPT_E_INVALID; }
 
+int adypt_set_fused_bounces(adypt_ctx *c, int enabled)
+{
+	if(!c) return ADYPT_E_INVALID;
+	c->fused_bounces = enabled ? 1 : 0; // takes effect with the next batch; both pipelines leave the same image and the same state behind
+	return ADYPT_OK;
+}
+
+int adypt_get_fused_bounces(const adypt_ctx *c) { return c ? (c->last_batch_fused ? 1 : 0) : ADYPT_E_INVALID; }
+
 int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 {
 	if(!c) return ADYPT_E_INVALID;
@@ -1164,6 +1170,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		}
 		// every bounce after the first in ONE launch (k_path): the reference's for(b < uMaxBounce) inside a single dispatch
 		const bool fused_bounces = fused_first && n_pipes == 1 && c->fused_bounces && (int64_t)m * (int64_t)c->n_local_px <= kPathMaxPaths;
+		c->last_batch_fused = fused_bounces;
 		if(fused_bounces && max_bounce > 1)
 		{
 			const Pipe &pipe = c->pipes[0];
@@ -1370,6 +1377,8 @@ int adypt_get_stats(adypt_ctx *c, adypt_stats *out)
 	out->rays = st.rays; out->nodes_visited = st.nodes; out->tris_tested = st.tris; out->hits = st.hits; out->shaded = st.shaded;
 	out->stack_overflows = st.overflows; out->bad_materials = st.bad_materials; out->max_stack = st.max_stack;
 	out->trace_launches = c->trace_launches; out->trace_ms = c->trace_ms; out->shade_ms = c->shade_ms;
+	out->path_ms = c->path_ms; out->path_launches = c->path_launches; out->reserved = 0;
+	out->path_rays = st.path_rays; out->path_nodes = st.path_nodes; out->path_tris = st.path_tris; out->path_hits = st.path_hits; out->path_shaded = st.path_shaded;
 	return ADYPT_OK;
 }
 
@@ -1404,7 +1413,7 @@ int adypt_reset_stats(adypt_ctx *c)
 	// on the context's own stream: a legacy-stream hipMemset is not ordered against a non-blocking stream
 	HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(DeviceStats), c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	c->trace_ms = c->shade_ms = 0; c->trace_launches = 0;
+	c->trace_ms = c->shade_ms = c->path_ms = 0; c->trace_launches = c->path_launches = 0;
 	return ADYPT_OK;
 }
 

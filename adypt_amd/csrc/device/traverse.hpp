@@ -22,26 +22,6 @@
 #pragma once
 #include "shade.hpp"
 
-// Measurement hooks: empty in the product.  A measurement-only build (-DADYPT_MEASUREMENT_BUILD -DADYPT_ABLATE_<what>, tools/ab.py)
-// takes their bodies — deliberately redundant loads / instructions that price a pipeline — from csrc/measure/k_trace_ablations.hpp.
-#ifdef ADYPT_MEASUREMENT_BUILD
-#include "../measure/k_trace_ablations.hpp"
-#else
-#define ADYPT_MEASURE_AFTER_TRI_LOADS(w0)
-#define ADYPT_MEASURE_AFTER_NODE_LOADS(np, lane)
-#define ADYPT_MEASURE_AFTER_SLAB_TEST(aox, aoy, aoz, aix, aiy)
-#endif
-#ifndef ADYPT_MEASURE_FP16_NODES
-#define ADYPT_MEASURE_MORE_NODE_REGS()
-#define ADYPT_MEASURE_LOAD_MORE_NODE(np)
-#endif
-#ifndef ADYPT_MEASURE_WAVE_TIMELINE
-#define ADYPT_MEASURE_WAVE_BEGIN()
-#define ADYPT_MEASURE_WAVE_FIRST_RAYS()
-#define ADYPT_MEASURE_WAVE_QUEUE_DRY()
-#define ADYPT_MEASURE_WAVE_END(stats)
-#endif
-
 namespace adypt {
 
 constexpr int kRefillMin = 16; // default: refill when at least this many lanes of the wave are idle (or all are)
@@ -49,9 +29,7 @@ constexpr int kChunk = 128;    // default: rays a workgroup reserves per queue a
 constexpr int kBite = 32;      // default: rays a wave takes from its workgroup's reservation at a time (end of a launch)
 constexpr int kEndgame = 4;    // default: the end of a launch = fewer than this many more chunks per wave left in the segment
 struct WgPool { unsigned long long range; uint32_t lock, dry; }; // range = (end << 32) | next: reserved, not yet handed to a wave
-#ifndef ADYPT_MEASURE_FP16_NODES
 constexpr int kNodeUint4 = 5;  // the 80-byte WideBVHNode, verbatim (src/BVH/WideBVH.hpp:13-26)
-#endif
 
 // Reserve up to `want` consecutive rays: first from the segment of "our" XCD (blockIdx & 7 groups the workgroups
 // that share an L2 under the observed round-robin dispatch — a speed hint only), then steal from the others.
@@ -107,7 +85,6 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
 	const int home = blockIdx.x & (kNumSegments - 1);
 
-	ADYPT_MEASURE_WAVE_BEGIN();
 	// the clock the chip holds under THIS launch: shader cycles (s_memtime) against the constant 100 MHz counter (s_memrealtime) over the life
 	// of workgroup 0's first wave — bench.py's vector-ALU roof is 1024 SIMDs x this, measured in the run it prices (adypt_get_shader_clock)
 	const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
@@ -212,8 +189,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 					}
 				}
 				loc_next = cb; loc_end = cb + cn;
-				if(cn == 0 && dry) { exhausted = true; ADYPT_MEASURE_WAVE_QUEUE_DRY(); }
-				else if(cn) { ADYPT_MEASURE_WAVE_FIRST_RAYS(); }
+				if(cn == 0 && dry) exhausted = true;
 			}
 			const uint32_t begin = loc_next;
 			const uint32_t got = min(n_idle, loc_end - loc_next);
@@ -285,7 +261,6 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 		if(a.packed) st3((float *)a.hit, ray, __int_as_float(tri_id), hit_u, hit_v);
 		else a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
 	}
-	ADYPT_MEASURE_WAVE_END(a.stats);
 	if(blockIdx.x == 0 && threadIdx.x == 0)
 	{
 		atomicAdd(&a.stats->clock_cycles, __builtin_readcyclecounter() - clk_c0);

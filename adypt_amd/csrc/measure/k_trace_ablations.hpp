@@ -1,7 +1,8 @@
-// MEASUREMENT ONLY — never part of the shipped library (adypt_amd/csrc/Makefile does not define ADYPT_MEASUREMENT_BUILD).
-// Bodies of the hooks in device/traverse.hpp: redundant work that prices one pipeline of the CU at a time.  Results stay correct with
-// every one of them (the extra loads / adds feed nothing); the numbers they produced are in profiles/r2_ablations_k_trace.txt.
-//   make -C adypt_amd/csrc HIPFLAGS="$(HIPFLAGS) -DADYPT_MEASUREMENT_BUILD -DADYPT_ABLATE_EXTRA_LOADS" OUT=... ; tools/ab.py default <variant>.so
+// MEASUREMENT ONLY — never part of the shipped library: the product sources do not mention this file or its hooks.
+// Bodies of the hook points that csrc/measure/k_trace_hooks.py puts into a scratch copy of the device sources: redundant work that prices one
+// pipeline of the CU at a time.  Results stay correct with every one of them except SHADE_TRI_L2 and FP16_NODES' node layout (bit-identical
+// images, different upload); the numbers they produced are in profiles/r2_ablations_k_trace.txt and profiles/r3_ablations_k_trace.txt.
+//   tools/build_variant.sh <name> --transform adypt_amd/csrc/measure/k_trace_hooks.py -DADYPT_ABLATE_EXTRA_LOADS ; tools/ab.py default <name>
 #pragma once
 
 #ifdef ADYPT_ABLATE_EXTRA_TRI_LOADS   // the triangle loads a second time (L1 hits)

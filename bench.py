@@ -1,33 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the hot path (BASELINE.json): Mrays/s (primary + secondary) of the wavefront
-path tracer on the Sponza-class scene, 1920x1080, 8 bounces, with the roofline of the dominant kernel (the CWBVH8
-traversal) and a CPU baseline (the oracle's scalar traversal) timed on the same box.
+"""bench.py — headline benchmark of the hot path (BASELINE.json): Mrays/s (primary + secondary) of the wavefront path tracer on the
+Sponza-class scene, 1920x1080, 8 bounces, with the roofline of the dominant kernel and a CPU baseline (the oracle's scalar traversal)
+timed on the same box.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one path-traced frame (1 spp) of the whole 1920x1080 image = one pass of the hot path over one batch:
-camera rays -> [traversal -> shade/scatter] x 8 -> accumulate.  With N > 1 the frame is sharded by 32x32 pixel tile
-over the ranks (zero communication while rendering) and the timed region ends with the single gather of the fp32
-radiance on rank 0 (RCCL over xGMI, inside the library: adypt_comm_gather_radiance).  Total work is fixed as N grows ->
-"scaling": "strong".  The launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT: the product needs no torch
-(`--comm torch` keeps the torch.distributed variant: barrier / reductions / gather through torch, backend nccl = RCCL).
+One "step" = one path-traced frame (1 spp) of the whole 1920x1080 image = one pass of the hot path over one batch: camera rays /
+cached primary hits -> bounce 0 (k_shade_first) -> every further bounce in ONE launch (k_path: traversal + shading) -> accumulate.
+The timed region (W untimed warm-up steps, then exactly K steps between barriers) is repeated R times from the same start frame;
+`value` is the median, the spread is printed beside it.
+
+N > 1: the frame is sharded by 32x32 pixel tile over the GPUs (zero communication while rendering) and the timed region ends with the
+single gather of the fp32 radiance on GPU 0 (RCCL over xGMI, inside the library).  Total work is fixed as N grows -> "scaling": "strong".
+Two ways to get N GPUs, the same tile shard and gather either way:
+  * started by a launcher (WORLD_SIZE = N): one process per GPU, adypt_comm_* (ncclCommInitRank);
+  * started plainly as `python bench.py --gpus N`: ONE process drives the N devices through adypt_create_multi (ncclCommInitAll) — and
+    exits non-zero if the box has fewer than N devices.  It never falls back to fewer GPUs than asked for.
 
 What the JSON line carries besides the contract's fields:
-  roofline               the traversal kernel on the bench scene.  Its BVH (19 MB) is cache resident, so the HBM roof does not
-                         bind; the kernel is bound by vector-ALU issue (with the CU's vector-memory pipeline close behind) ->
-                         bound "valu_issue", achieved = vector-ALU issue cycles demanded per second (PMC instructions per ray x
-                         measured rays/s of the kernel x the average architectural issue cycles of its instruction mix) against
-                         1024 SIMDs x the clock the chip ran the kernel at (PMC); lane_util = fraction of the 64 lanes doing work in an issued instruction.  The algorithmic
-                         HBM-read figure of SURVEY.md §8(d) and the measured fabric traffic are reported next to it.
-  roofline_hbm_resident  the same kernel on the ~10 M-triangle stand-in of BASELINE config 4 (BVH 0.6 GB > 256 MB Infinity
-                         Cache): here HBM binds -> bound "hbm", algorithmic bytes / HIP-event time / 8 TB/s.
+  roofline               the dominant kernel of the timed region (k_path<false>: 98 % of the GPU time): bound "hbm" as the metric's name
+                         asks — achieved = fabric-side bytes the counters saw per ray (committed rocprofv3 --pmc passes of this very
+                         command, hash-checked against the device sources) x this run's rays/s of the kernel (HIP events); the
+                         algorithmic-bytes figure of SURVEY.md 8(d) beside it (it exceeds the peak on this cache-resident scene), and
+                         what really binds the kernel: vector-ALU issue (`valu_issue` sub-block).
+  roofline_hbm_resident  the same kernel on the ~10 M-triangle stand-in of BASELINE config 4 (BVH 0.6 GB > 256 MB Infinity Cache).
+  primary_only           BASELINE config 2: primary rays only (adypt_trace_primary), >= 100 calls.
+  tmp_lifetime_1         the K steps with every frame tracing its primary rays (report tmpLifetime 16 and 1).
   single_frame           one adypt_trace_spp(ctx, 1) per call (what Instance::Update does), with the library's look-ahead.
   cpu_baseline           oracle/liboracle.so on the host cores, bounded sample.
 
-Scene: the real sponza.obj is not available anywhere (no network); a deterministic procedural stand-in of the same
-triangle count is generated, written as OBJ/MTL + Adypt .config and loaded through the product's own
-loader -> SBVH -> CWBVH8 path (adypt_amd/scenes.py).  `$ADYPT_ASSETS/sponza.obj` is used instead when present.
+Scene: the real sponza.obj is not available anywhere (no network); a deterministic procedural stand-in of the same triangle count is
+generated, written as OBJ/MTL + Adypt .config and loaded through the product's own loader -> SBVH -> CWBVH8 path (adypt_amd/scenes.py).
+`$ADYPT_ASSETS/sponza.obj` is used instead when present.
 """
 import argparse
 import json
@@ -43,7 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec)
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
 NOMINAL_CLOCK_GHZ = 2.4 # only used when no profile supplies the clock the chip really ran the kernel at
-PMC_BENCH, PMC_SANMIGUEL, ISSUE_MODEL = "r3_pmc_bench.json", "r3_pmc_sanmiguel.json", "r3_valu_issue_model.json"
+PMC_BENCH, PMC_SANMIGUEL, ISSUE_MODEL = "r4_pmc_bench.json", "r4_pmc_sanmiguel.json", "r4_valu_issue_model.json"
 PT_CFG = {"maxBounce": 8, "subpixel": 8, "clamp": 4.0, "sun": [12.0, 11.0, 10.0], "stackSize": 24}
 SEED = 12345
 
@@ -56,7 +61,7 @@ def load_profile(name):
 
 
 def counter_figures(name):
-    """Per-ray counter figures of the traversal kernel from the committed rocprofv3 --pmc passes (tools/collect_profiles.sh ->
+    """Per-ray counter figures of the dominant kernel from the committed rocprofv3 --pmc passes (tools/collect_profiles.sh ->
     tools/pmc_profile.py), or None with the reason when the file is missing or was measured on other device sources."""
     from tools.source_hash import device_source_hash
     pmc = load_profile(name)
@@ -69,19 +74,14 @@ def counter_figures(name):
 
 
 def valu_roofline(pmc, model, kernel_rays_s, live_clock_ghz=0.0):
-    """The vector-ALU issue roof of the traversal kernel.  Everything is a formula over the committed profiles and ONE live number:
-      peak      = 1024 SIMDs x effective clock; effective clock = shader cycles / 100 MHz ticks sampled inside this run's traversal launches
-                  (fallback: GRBM_GUI_ACTIVE / 8 XCDs / launch duration of the profile run's kernel trace)
-      achieved  = issue cycles the kernel's vector-ALU instructions need per second = SQ_INSTS_VALU per ray (profile) x rays/s (live) x the
-                  average ARCHITECTURAL issue time of its instruction mix (2 cycles full-rate fp32 / logic / moves, 4 the other classes and
-                  packed fp32, 8 transcendental: profiles/r3_valu_issue_model.json)
+    """The vector-ALU issue roof of the dominant kernel — what binds it on the cache-resident bench scene.
+      peak      = 1024 SIMDs x effective clock: shader cycles / 100 MHz ticks sampled inside THIS run's launches (adypt_get_shader_clock)
+      achieved  = issue cycles the kernel's vector-ALU instructions need per second = SQ_INSTS_VALU per ray (committed PMC pass) x rays/s
+                  (live) x the average ARCHITECTURAL issue time of its instruction mix (2 cycles full-rate fp32 / logic / moves, 4 the other
+                  classes, packed and 64-bit, 8 transcendental: tools/valu_issue_model.py)
       frac      = achieved / peak: a fraction of a roof no instruction stream can exceed.
-    Beside it: the same with the issue times measured on one-instruction loops (profiles/r3_valu_calibration.json, true cycles: 2.46 / 4.37 /
-    4.33 / 8.24).  That figure exceeds 1 — the kernel's mixed stream issues faster than the weighted sum of single-class loops — so the loops
-    are not a roof; it is printed because VERDICT r2 asked for both.  SQ_ACTIVE_INST_VALU is NOT used: the calibration shows it counts 1 per
-    instruction (2 per transcendental) whatever the instruction's issue time."""
-    # the clock: measured inside this run's own traversal launches (s_memtime / s_memrealtime, adypt_get_shader_clock) when available —
-    # boxes of the pool hold 2.1-2.3 GHz under this kernel — otherwise the one of the profile run (GRBM_GUI_ACTIVE / 8 / kernel-trace duration)
+    `frac_at_single_class_loop_rates`: the same with the class times measured on one-instruction loops (profiles/r3_valu_calibration.json);
+    it can exceed 1 — a mixed stream issues faster than the weighted sum of single-class loops — so those are not a roof."""
     profile_clock = pmc.get("effective_clock_GHz")
     clock = live_clock_ghz if live_clock_ghz and live_clock_ghz > 0.5 else profile_clock
     peak = N_SIMD * (clock or NOMINAL_CLOCK_GHZ)
@@ -90,7 +90,8 @@ def valu_roofline(pmc, model, kernel_rays_s, live_clock_ghz=0.0):
     achieved = inst_rate * arch / 1e9
     frac = achieved / peak
     out = {"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "Gcycle/s", "frac": round(frac, 4),
-           "effective_clock_GHz": round(clock, 3) if clock else None, "clock_source": "live: s_memtime / s_memrealtime inside this run's traversal launches" if clock == live_clock_ghz else "profile run",
+           "effective_clock_GHz": round(clock, 3) if clock else None,
+           "clock_source": "live: s_memtime / s_memrealtime inside this run's launches" if clock == live_clock_ghz else "profile run",
            "effective_clock_GHz_in_profile_run": round(profile_clock, 3) if profile_clock else None, "lane_util": round(pmc["lane_util"], 4),
            "useful_frac": round(min(1.0, frac) * pmc["lane_util"], 4),
            "valu_insts_per_ray": round(pmc["valu_insts_per_ray"], 2), "valu_Ginst_s": round(inst_rate / 1e9, 1),
@@ -116,9 +117,17 @@ def traffic_fields(pmc, rays, launches, kernel_rays_s):
             "l2_hit_rate": round(pmc.get("TCC_hit_rate", 0.0), 3)}
 
 
+def dominant(st):
+    """Which kernel the roofline is about: k_path when the batches ran their bounces in one launch, else the traversal kernel."""
+    if st.get("path_launches", 0) > 0:
+        return {"kernel": "k_path<false>", "ms": st["path_ms"], "launches": st["path_launches"], "rays": st["path_rays"], "fused": True}
+    return {"kernel": "k_trace<false, false>", "ms": st["trace_ms"], "launches": st["trace_launches"], "rays": st["rays"], "fused": False}
+
+
 def census(pt, steps, warmup, expect_rays=None):
-    """The same K frames again through the instrumented traversal -> exact node / triangle counts -> algorithmic bytes
-    (per ray 80 B x nodes visited + 48 B x triangles tested + 4 B x hit remap + 32 B ray read + 16 B hit write)."""
+    """The same K frames again through the instrumented kernels -> exact node / triangle / hit / shaded counts -> algorithmic bytes of
+    SURVEY.md 8(d): per ray 80 B x nodes visited + 48 B x triangles tested + 4 B x hit remap + 32 B ray read + 16 B hit write; full path
+    tracing adds 164 B (triangle 100 + material 64) per shaded hit.  For the dominant kernel alone when it is k_path (its own counters)."""
     pt.Reset()
     pt.SetInstrumentation(timing=False, counters=True)
     if warmup:
@@ -130,11 +139,49 @@ def census(pt, steps, warmup, expect_rays=None):
     if expect_rays is not None:
         assert cs["rays"] == expect_rays, "census pass traced a different number of rays"
     cs["alg_bytes"] = 80 * cs["nodes_visited"] + 48 * cs["tris_tested"] + 4 * cs["hits"] + 48 * cs["rays"]
+    if cs.get("path_rays", 0):
+        cs["k_rays"], cs["k_nodes"], cs["k_tris"], cs["k_hits"], cs["k_shaded"] = cs["path_rays"], cs["path_nodes"], cs["path_tris"], cs["path_hits"], cs["path_shaded"]
+        cs["k_alg_bytes"] = 80 * cs["k_nodes"] + 48 * cs["k_tris"] + 4 * cs["k_hits"] + 48 * cs["k_rays"] + 164 * cs["k_shaded"]
+    else:
+        cs["k_rays"], cs["k_nodes"], cs["k_tris"], cs["k_hits"], cs["k_shaded"] = cs["rays"], cs["nodes_visited"], cs["tris_tested"], cs["hits"], 0
+        cs["k_alg_bytes"] = cs["alg_bytes"]
     return cs
 
 
+def roofline_block(dom, cs, pmc_name, live_clock, bvh_mb, note_extra=""):
+    """The contract's roofline object for the dominant kernel (`dom`: name, HIP-event ms, launches, rays of the timed region; `cs`: census)."""
+    ms, launches, rays = dom["ms"], max(1, dom["launches"]), dom["rays"]
+    rays_s = rays / (ms * 1e-3) if ms > 0 else 0.0
+    alg_gbs = cs["k_alg_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    out = {"kernel": dom["kernel"], "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_rays": int(rays), "kernel_rays_warmup": int(dom.get("rays_warmup", 0)),
+           "launches": int(dom["launches"]), "avg_launch_ms": round(ms / launches, 4), "kernel_Mrays_s": round(rays_s / 1e6, 1),
+           "alg_bytes_per_launch": round(cs["k_alg_bytes"] / launches), "alg_bytes_per_ray": round(cs["k_alg_bytes"] / max(1, cs["k_rays"]), 1),
+           "nodes_per_ray": round(cs["k_nodes"] / max(1, cs["k_rays"]), 2), "tris_per_ray": round(cs["k_tris"] / max(1, cs["k_rays"]), 2),
+           "shaded_per_ray": round(cs["k_shaded"] / max(1, cs["k_rays"]), 3),
+           "alg_GBs": round(alg_gbs, 1), "alg_frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "shader_clock_GHz_live": round(live_clock, 3)}
+    pmc, why = counter_figures(pmc_name)
+    if pmc and pmc.get("kernel") != dom["kernel"]:
+        pmc, why = None, "profiles/%s holds %s, this run's dominant kernel is %s" % (pmc_name, pmc.get("kernel"), dom["kernel"])
+    if pmc:
+        out.update(traffic_fields(pmc, rays, launches, rays_s))
+        out.update({"achieved": out["traffic_GBs"], "frac": out["traffic_frac_of_hbm_peak"], "pmc_stale": False,
+                    "traffic_over_algorithmic": round(pmc["traffic_bytes_per_ray"] / (cs["k_alg_bytes"] / max(1, cs["k_rays"])), 3),
+                    "valu_issue": valu_roofline(pmc, load_profile(ISSUE_MODEL), rays_s, live_clock),
+                    "note": "achieved / frac / traffic = fabric-side bytes of this kernel's launches (PMC FETCH_SIZE x 2 + WRITE_SIZE per ray, %s) x this run's "
+                            "rays/s of the kernel (HIP events on the context's stream) against 8 TB/s: an upper bound on HBM bytes (Infinity-Cache hits are in it).  "
+                            "alg_GBs / alg_frac_of_hbm_peak = SURVEY.md 8(d) bytes (exact census of the same frames) / the same time: NOT a fraction of HBM "
+                            "traffic when it exceeds traffic — the BVH (%.0f MB) is served by the L2s (l2_hit_rate) and the Infinity Cache.  What binds the kernel "
+                            "on this scene is vector-ALU issue: valu_issue (peak = 1024 SIMDs x the clock sampled inside this run's launches; achieved = "
+                            "SQ_INSTS_VALU per ray x rays/s x the mix's architectural issue cycles, profiles/%s)%s" % (pmc.get("command", "?"), bvh_mb, ISSUE_MODEL, note_extra)})
+    else:
+        out.update({"achieved": round(alg_gbs, 1), "frac": round(alg_gbs / HBM_PEAK_GBS, 4), "traffic": None, "pmc_stale": True,
+                    "note": "no counter figures: " + why + ".  achieved / frac fall back to SURVEY.md 8(d) algorithmic bytes / HIP-event time / 8 TB/s, which for an "
+                            "L2 / Infinity-Cache resident BVH (%.0f MB) can exceed 1 and is not a fraction of HBM traffic" % bvh_mb})
+    return out
+
+
 def hbm_resident_block(args, dev):
-    """roofline_hbm_resident: the traversal kernel where HBM binds (BASELINE config 4 stand-in, BVH 0.6 GB)."""
+    """roofline_hbm_resident: the dominant kernel where memory, not instruction issue, is what it waits for (BASELINE config 4 stand-in)."""
     from adypt_amd import api, scenes
     t0 = time.time()
     spec = scenes.make_scene("sanmiguel", args.cache, width=1920, height=1080, pt=dict(PT_CFG, tmpLifetime=16))
@@ -145,6 +192,7 @@ def hbm_resident_block(args, dev):
     steps, warmup = 32, 16
     pt.SetInstrumentation(timing=True, counters=False)
     pt.Trace(True, warmup)
+    warm = dominant(pt.GetStats())
     pt.ResetStats()
     t1 = time.perf_counter()
     pt.Trace(True, steps)
@@ -153,35 +201,13 @@ def hbm_resident_block(args, dev):
     live_clock = pt.GetShaderClockGHz()
     cs = census(pt, steps, warmup, st["rays"])
     bvh_mb = (len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 52) / 1e6
-    achieved = cs["alg_bytes"] / (st["trace_ms"] * 1e-3) / 1e9
-    rays_s = st["rays"] / (st["trace_ms"] * 1e-3)
-    out = {"kernel": "k_trace<false, false>",
-           "workload": "sanmiguel-like procedural stand-in (%s), %d triangles, BVH %.0f MB (nodes + Woop + index) > 256 MB Infinity Cache, 1920x1080, 8 bounces, %d frames after %d warm-up"
-                       % (spec.label, inst.scene.n_tris, bvh_mb, steps, warmup),
-           "alg_GBs": round(achieved, 1), "alg_frac_of_hbm_peak": round(achieved / HBM_PEAK_GBS, 4), "hbm_peak_GBs": HBM_PEAK_GBS,
-           "launches": int(st["trace_launches"]), "avg_launch_ms": round(st["trace_ms"] / max(1, st["trace_launches"]), 4),
-           "alg_bytes_per_launch": round(cs["alg_bytes"] / max(1, st["trace_launches"])), "alg_bytes_per_ray": round(cs["alg_bytes"] / cs["rays"], 1),
-           "nodes_per_ray": round(cs["nodes_visited"] / cs["rays"], 2), "tris_per_ray": round(cs["tris_tested"] / cs["rays"], 2),
-           "trace_kernel_Mrays_s": round(rays_s / 1e6, 1), "whole_frame_Mrays_s": round(st["rays"] / wall / 1e6, 1),
-           "trace_kernels_ms": round(st["trace_ms"], 2), "shade_kernels_ms": round(st["shade_ms"], 2), "setup_s": round(setup_s, 1)}
-    pmc, why = counter_figures(PMC_SANMIGUEL)
-    if pmc:
-        out.update(traffic_fields(pmc, st["rays"], st["trace_launches"], rays_s))
-        valu = valu_roofline(pmc, load_profile(ISSUE_MODEL), rays_s, live_clock)
-        # what binds here is neither roof alone: the fraction reported is the counter-measured fabric traffic against the HBM peak — a valid
-        # fraction (an upper bound on HBM bytes: Infinity-Cache hits are in it); the algorithmic figure exceeds what reaches the fabric because
-        # the L2s catch the top of the tree, and the vector ALUs are busy for valu_issue_frac of the cycles
-        out.update({"bound": "between hbm and valu_issue", "achieved": out["traffic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": out["traffic_frac_of_hbm_peak"], "valu_issue_frac": valu["frac"], "lane_util": valu["lane_util"],
-                    "effective_clock_GHz": valu["effective_clock_GHz"], "pmc_stale": False,
-                    "traffic_over_algorithmic": round(pmc["traffic_bytes_per_ray"] / (cs["alg_bytes"] / cs["rays"]), 3),
-                    "note": "achieved / frac = fabric-side bytes of the traversal launches (PMC FETCH_SIZE x 2 + WRITE_SIZE of %s, per ray) x this run's rays/s "
-                            "against 8 TB/s; traffic_uncorrected = the same without the x 2.  alg_frac_of_hbm_peak (SURVEY.md 8d bytes / HIP-event time / 8 TB/s) "
-                            "is NOT a fraction of HBM traffic: the L2s catch %.0f %% of the requests.  valu_issue_frac: bench.py valu_roofline()"
-                            % (pmc.get("command", "?"), 100 * pmc.get("TCC_hit_rate", 0.0))})
-    else:
-        out.update({"bound": "hbm (algorithmic bytes only)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                    "traffic": None, "pmc_stale": True, "note": "no counter figures: " + why + "; alg_frac_of_hbm_peak is cache assisted and not reported as a fraction"})
+    out = roofline_block(dict(dominant(st), rays_warmup=warm["rays"]), cs, PMC_SANMIGUEL, live_clock, bvh_mb)
+    out.update({"workload": "sanmiguel-like procedural stand-in (%s), %d triangles, BVH %.0f MB (nodes + Woop + index) > 256 MB Infinity Cache, 1920x1080, 8 bounces, %d frames after %d warm-up"
+                            % (spec.label, inst.scene.n_tris, bvh_mb, steps, warmup),
+                "whole_frame_Mrays_s": round(st["rays"] / wall / 1e6, 1), "trace_kernels_ms": round(st["trace_ms"], 2), "other_kernels_ms": round(st["shade_ms"], 2),
+                "setup_s": round(setup_s, 1)})
+    if "valu_issue" in out:
+        out["bound"] = "between hbm and valu_issue"
     pt.destroy()
     return out
 
@@ -223,23 +249,30 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--repeats", type=int, default=7, help="the timed region (warm-up + K steps from the same start frame) is run this many times; value = median")
     ap.add_argument("--scene", default="sponza")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--tmp-lifetime", type=int, default=16, help="reference default 16: primary hits are re-traced every 16th frame")
     ap.add_argument("--comm", default=os.environ.get("ADYPT_BENCH_COMM", "native"), choices=["native", "torch"],
-                    help="N > 1: 'native' = the library's own RCCL communicator (no torch); 'torch' = torch.distributed (nccl, or gloo with ADYPT_BENCH_BACKEND=gloo)")
+                    help="one process per GPU (launcher): 'native' = the library's own RCCL communicator (no torch); 'torch' = torch.distributed (nccl, or gloo with ADYPT_BENCH_BACKEND=gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-block", action="store_true", help="skip roofline_hbm_resident (the 10 M-triangle scene: ~25 s of setup)")
     ap.add_argument("--no-single-frame", action="store_true")
+    ap.add_argument("--no-extra-blocks", action="store_true", help="skip primary_only and tmp_lifetime_1")
     ap.add_argument("--cache", default=os.environ.get("ADYPT_CACHE", os.path.join(ROOT, ".adypt_cache")))
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.repeats < 1:
+        raise SystemExit("bench.py: --gpus, --steps, --repeats must be >= 1 and --warmup >= 0")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # no launcher and more than one GPU asked for: ONE process drives all of them (adypt_create_multi, ncclCommInitAll)
+    multi = world == 1 and args.gpus > 1
+    n_gpus = args.gpus
     use_torch = world > 1 and args.comm == "torch"
     dev = int(os.environ.get("ADYPT_BENCH_DEVICE", local_rank))  # the override only to rehearse N ranks on a 1-GPU box
     dist = torch = None
@@ -268,16 +301,30 @@ def main() -> None:
     t_setup = time.time()
     spec = scenes.make_scene(args.scene, cache, width=args.width, height=args.height, pt=pt_cfg)
     inst = api.Instance()
+    shared_hook = multi and os.environ.get("ADYPT_MULTI_SHARED_DEVICE", "0") not in ("", "0")  # TEST HOOK: N tile shards on ONE device (not a measurement)
     try:
-        ok = inst.InitializeFromFile(spec.config_path, shift_seed=SEED, device=dev, tile_rank=rank, tile_nranks=world)
+        if multi:
+            ok = inst.InitializeFromFile(spec.config_path, shift_seed=SEED, devices=[0] * n_gpus if shared_hook else list(range(n_gpus)))
+        else:
+            ok = inst.InitializeFromFile(spec.config_path, shift_seed=SEED, device=dev, tile_rank=rank, tile_nranks=world)
     except N.AdyptError as e:
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path (%s)" % e)
+        raise SystemExit("bench.py --gpus %d: cannot create the tracer on %s (%s).  The product has no CPU path and bench.py never runs on fewer GPUs than asked for."
+                         % (n_gpus, "devices 0..%d" % (n_gpus - 1) if multi else "device %d" % dev, e))
     assert ok, api.InstanceConfig.last_error()
     pt = inst.m_path_tracer
     c = inst.m_config.c
     fif = pt.GetFramesInFlight()
     t_setup = time.time() - t_setup
+    comm_ranks = 0
 
+    if multi and not shared_hook:
+        try:
+            pt.CommInit()  # ncclCommInitAll over the N devices, before anything is timed
+        except (N.AdyptError, OSError) as e:
+            raise SystemExit("bench.py --gpus %d: RCCL communicator over devices 0..%d failed (%s)" % (n_gpus, n_gpus - 1, e))
+        comm_ranks = pt.CommRanks()
+        if comm_ranks != n_gpus:
+            raise SystemExit("bench.py --gpus %d: the RCCL communicator reports %d ranks" % (n_gpus, comm_ranks))
     if world > 1 and not use_torch:
         # Two failure classes.  (a) rank 0 cannot even make an RCCL id (library not found, symbol missing): it leaves a marker in the
         # rendezvous file, EVERY rank sees the same RuntimeError, and all of them take the torch.distributed variant of the same gather
@@ -295,6 +342,7 @@ def main() -> None:
                 pt.CommBarrier()
             except (N.AdyptError, OSError) as e:
                 raise SystemExit("bench.py rank %d: native RCCL communicator failed (%s)" % (rank, e))
+            comm_ranks = pt.CommRanks()
             if rank == 0:  # every rank holds the communicator now: a later job must never find this id
                 try:
                     os.remove(D.rendezvous_path())
@@ -315,6 +363,12 @@ def main() -> None:
             if on_device:
                 return D.gather_radiance_device(gather_buf, pt, c.width, c.height, rank, world)
             return D.gather_radiance(gather_buf, c.width, c.height, rank, world)
+    elif multi:
+        def barrier():
+            pt.DeviceSynchronize()  # every device drained (hipDeviceSynchronize each); one process: nothing else to meet
+
+        def gather():
+            return pt.GatherDevice()  # grouped ncclSend / ncclRecv into device 0 + un-tiling there; returns after all streams have drained
     else:
         def barrier():
             # every rank's GPU drained (hipDeviceSynchronize), then all ranks met (RCCL all-reduce + drain)
@@ -325,38 +379,55 @@ def main() -> None:
         def gather():
             return pt.CommGatherDevice()  # the one collective of the data path; rank 0: the assembled image, resident in HBM
 
-    # ---- warmup ------------------------------------------------------------------------------------------------------
-    pt.SetInstrumentation(timing=True, counters=False)
-    if args.warmup:
-        pt.Trace(True, args.warmup)
-    gather()  # warms the communicator
-    rays_warmup = int(pt.GetStats()["rays"])
-    pt.ResetStats()
+    def reduce_max(x):
+        if use_torch:
+            t = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return pt.CommAllReduce([x], "max")[0] if world > 1 else x
 
-    # ---- timed region: exactly K steps + the one gather ------------------------------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    pt.Trace(True, args.steps)
-    t_gather = time.perf_counter()
-    image = gather()  # rank 0: the assembled W x H x 3 radiance, resident in HBM (as the reference's result texture is)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gather_ms = (time.perf_counter() - t_gather) * 1e3
-    st = pt.GetStats()
-    live_clock = pt.GetShaderClockGHz()  # the clock the chip held under the traversal launches of the timed region
-    # per-rank breakdown, so that a scaling run can be diagnosed from its own line: every rank fills its own slots, one sum all-reduce
-    # hands every rank the whole table (5 x N doubles)
-    mine = [elapsed * 1e3, float(st["trace_ms"]), float(st["shade_ms"]), gather_ms, float(st["rays"])]
+    # ---- the timed region, R times from the same start frame: W untimed warm-up steps, then exactly K steps + the one gather ------------
+    pt.SetInstrumentation(timing=True, counters=False)
+    repeats = []
+    image = None
+    for rep in range(args.repeats):
+        pt.Reset()
+        if args.warmup:
+            pt.Trace(True, args.warmup)
+        gather()  # warms the communicator; the warm-up frames are done
+        if rep == 0:
+            warm_stats = pt.GetStats()
+            rays_warmup = int(warm_stats["rays"])
+        pt.ResetStats()
+        barrier()
+        t0 = time.perf_counter()
+        pt.Trace(True, args.steps)
+        t_gather = time.perf_counter()
+        image = gather()  # rank 0 / device 0: the assembled W x H x 3 radiance, resident in HBM (as the reference's result texture is)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        gather_ms = (time.perf_counter() - t_gather) * 1e3
+        st = pt.GetStats()
+        repeats.append({"elapsed_all_ranks": reduce_max(elapsed), "elapsed": elapsed, "gather_ms": gather_ms, "st": st, "clock": pt.GetShaderClockGHz()})
+    order = sorted(range(len(repeats)), key=lambda i: repeats[i]["elapsed_all_ranks"])
+    med = repeats[order[len(order) // 2]]  # the median repeat: its kernel timings are the ones reported
+    elapsed, gather_ms, st, live_clock = med["elapsed_all_ranks"], med["gather_ms"], med["st"], med["clock"]
+
+    # per-device breakdown, so that a scaling run can be diagnosed from its own line
+    mine = [med["elapsed"] * 1e3, float(st["trace_ms"]), float(st["shade_ms"]), gather_ms, float(st["rays"])]
     per_rank = None
-    if use_torch:
+    if multi:
+        cstats = [pt.ContextStats(i) for i in range(n_gpus)]  # the counters / kernel timings of the last repeat, per device
+        per_rank = np.array([[med["elapsed"] * 1e3, float(s["trace_ms"]), float(s["shade_ms"]), gather_ms, float(s["rays"])] for s in cstats])
+        total_rays = int(st["rays"])
+        image = pt.ReadResult()
+    elif use_torch:
         if image is not None and on_device:
             image = image.cpu().numpy()
         red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         rays = torch.tensor([int(st["rays"])], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-        elapsed, total_rays = float(tt.item()), int(rays.item())
+        total_rays = int(rays.item())
         table = torch.zeros(5 * world, dtype=torch.float64, device=red_dev)
         table[5 * rank:5 * rank + 5] = torch.tensor(mine, dtype=torch.float64)
         dist.all_reduce(table, op=dist.ReduceOp.SUM)
@@ -366,115 +437,130 @@ def main() -> None:
             flat = [0.0] * (5 * world)
             flat[5 * rank:5 * rank + 5] = mine
             per_rank = np.array(pt.CommAllReduce(flat, "sum")).reshape(world, 5)
-            elapsed = pt.CommAllReduce([elapsed], "max")[0]          # MAX over ranks
             total_rays = int(round(pt.CommAllReduce([float(st["rays"])], "sum")[0]))  # exact: < 2^53
         else:
             total_rays = int(st["rays"])
         image = pt.CommReadResult()  # untimed (collective): the image on the host for the checksum
 
-    # ---- census (untimed): the same K frames again through the instrumented traversal -> exact algorithmic bytes ------
-    trace_ms, trace_launches, shade_ms = st["trace_ms"], st["trace_launches"], st["shade_ms"]
-    cs = census(pt, args.steps, args.warmup, st["rays"])
-    alg_bytes = cs["alg_bytes"]
-    alg_gbs = alg_bytes / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
-    kernel_rays_s = st["rays"] / (trace_ms * 1e-3) if trace_ms > 0 else 0.0
-    bvh_mb = (len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 52) / 1e6
-    roofline = {"kernel": "k_trace<false, false>", "launches": int(trace_launches), "avg_launch_ms": round(trace_ms / max(1, trace_launches), 4),
-                "trace_kernel_Mrays_s": round(kernel_rays_s / 1e6, 1),
-                "alg_bytes_per_launch": round(alg_bytes / max(1, trace_launches)), "alg_bytes_per_ray": round(alg_bytes / max(1, cs["rays"]), 1),
-                "nodes_per_ray": round(cs["nodes_visited"] / max(1, cs["rays"]), 2), "tris_per_ray": round(cs["tris_tested"] / max(1, cs["rays"]), 2),
-                "alg_GBs": round(alg_gbs, 1), "alg_frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "hbm_peak_GBs": HBM_PEAK_GBS,
-                "traffic": None, "shader_clock_GHz_live": round(live_clock, 3)}
-    # The PMC counters cannot be read from inside this process: per-ray figures come from the committed rocprofv3 --pmc passes over
-    # this very command line (tools/collect_profiles.sh -> profiles/r3_pmc_bench.json), hash-checked against the device sources of this
-    # tree, x the rays / time measured here.  N > 1: rank 0 traces an interleaved 1/N of the same pixels with the same kernel.
-    pmc, why = counter_figures(PMC_BENCH) if (args.scene, args.width, args.height) == ("sponza", 1920, 1080) else (None, "no committed counter passes for this scene / size")
-    if pmc:
-        roofline.update(valu_roofline(pmc, load_profile(ISSUE_MODEL), kernel_rays_s, live_clock))
-        roofline.update(traffic_fields(pmc, st["rays"], trace_launches, kernel_rays_s))
-        roofline["note"] = ("BVH (nodes + Woop + index) %.0f MB is L2 / Infinity-Cache resident: alg_frac_of_hbm_peak may exceed 1 and is not a fraction of HBM "
-                            "traffic (traffic = what the counters saw on the fabric).  What binds is vector-ALU issue, the CU's vector-memory pipeline close behind "
-                            "(vmem_busy_est; profiles/r2_ablations_k_trace.txt).  peak = 1024 SIMDs x effective_clock_GHz (GRBM_GUI_ACTIVE / 8 / launch duration of "
-                            "the kernel trace); achieved = SQ_INSTS_VALU per ray (%s) x trace_kernel_Mrays_s of this run x issue_cycles_per_inst_architectural "
-                            "(the mix's 2 / 4 / 4 / 8-cycle classes, profiles/%s); frac_at_single_class_loop_rates = the same with the class times measured on "
-                            "one-instruction loops (profiles/r3_valu_calibration.json), > 1 because a mixed stream issues faster than those loops: not a roof.  "
-                            "lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)%s"
-                            % (bvh_mb, pmc.get("command", "?"), ISSUE_MODEL, "; per-ray figures of the 1-GPU passes applied to rank 0's shard" if world > 1 else ""))
-    else:
-        roofline.update({"bound": "hbm (algorithmic bytes; the scene is cache resident)", "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg_gbs / HBM_PEAK_GBS, 4), "pmc_stale": True,
-                         "note": "no counter figures: " + why + ".  Fallback to SURVEY.md 8d algorithmic bytes / HIP-event time / 8 TB/s, which for this "
-                                 "L2 / Infinity-Cache resident BVH (%.0f MB) can exceed 1 and is not a fraction of HBM traffic" % bvh_mb})
+    single_gpu = world == 1 and not multi
+    extras = single_gpu and rank == 0
+    roofline = primary_only = life1 = single = hbm = cpu = None
+    if extras:
+        # ---- census (untimed): the same K frames again through the instrumented kernels -> exact algorithmic bytes ------
+        dom = dict(dominant(st), rays_warmup=dominant(warm_stats)["rays"])
+        cs = census(pt, args.steps, args.warmup, st["rays"])
+        bvh_mb = (len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 52) / 1e6
+        on_bench_scene = (args.scene, args.width, args.height) == ("sponza", 1920, 1080)
+        roofline = roofline_block(dom, cs, PMC_BENCH if on_bench_scene else "(none for this scene / size)", live_clock, bvh_mb)
 
-    # The HBM-read roof of the metric's name, for the same kernel and launches: a valid fraction needs bytes that really travelled, so
-    # achieved = the counters' fabric-side traffic (an upper bound on HBM bytes: Infinity-Cache hits are in it); the algorithmic figure
-    # of SURVEY.md 8d is reported next to it and exceeds the peak on this cache-resident scene.
-    roofline_hbm = {"bound": "hbm", "kernel": "k_trace<false, false>", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "achieved": roofline.get("traffic_GBs"), "frac": roofline.get("traffic_frac_of_hbm_peak"), "traffic": roofline.get("traffic"),
-                    "algorithmic_GBs": round(alg_gbs, 1), "algorithmic_over_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": roofline["alg_bytes_per_launch"],
-                    "note": "achieved / frac from PMC traffic (None when the committed counter profile is stale); algorithmic_over_peak is not a fraction of HBM traffic: "
-                            "the 20 MB BVH is served by the L2s (hit rate in roofline.l2_hit_rate) and the Infinity Cache"}
+        if not args.no_extra_blocks:
+            # ---- BASELINE config 2: primary rays only (primaryray.glsl:46-94 -> adypt_trace_primary), one 2.07 M-ray launch per call ----
+            n_calls = 128
+            pt.SetInstrumentation(timing=True, counters=False)
+            for _ in range(8):
+                pt.Trace(False)
+            pt.ResetStats()
+            pt.DeviceSynchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_calls):
+                pt.Trace(False)
+            pt.DeviceSynchronize()
+            dt = time.perf_counter() - t1
+            s2 = pt.GetStats()
+            primary_only = {"workload": "BASELINE config 2: %dx%d, primary rays only, viewer type 0, %d calls of adypt_trace_primary (one traversal launch each)" % (c.width, c.height, n_calls),
+                            "rays_per_call": int(s2["rays"] // n_calls), "Mrays_s_per_call": round(s2["rays"] / dt / 1e6, 1), "ms_per_call": round(dt * 1e3 / n_calls, 4),
+                            "kernel_Mrays_s": round(s2["rays"] / s2["trace_ms"] / 1e3, 1), "kernel_ms_per_call": round(s2["trace_ms"] / n_calls, 4)}
+            # ---- the same K steps with tmpLifetime 1: every frame traces its primary rays ----
+            params = inst.m_config.pt_params(SEED)
+            params.tmp_lifetime = 1
+            pt.SetConfig(params)
+            pt.Reset()
+            if args.warmup:
+                pt.Trace(True, args.warmup)
+            pt.ResetStats()
+            pt.DeviceSynchronize()
+            t1 = time.perf_counter()
+            pt.Trace(True, args.steps)
+            pt.DeviceSynchronize()
+            dt = time.perf_counter() - t1
+            s3 = pt.GetStats()
+            life1 = {"workload": "the timed region's %d steps after %d warm-up with tmpLifetime 1 (no primary hit is cached)" % (args.steps, args.warmup),
+                     "Mrays_s": round(s3["rays"] / dt / 1e6, 1), "ms_per_step": round(dt * 1e3 / args.steps, 4), "rays_per_step": int(s3["rays"] // args.steps),
+                     "trace_kernels_ms": round(s3["trace_ms"], 2), "other_kernels_ms": round(s3["shade_ms"], 2)}
+            pt.SetConfig(inst.m_config.pt_params(SEED))
+            pt.Reset()
 
-    # ---- one frame per call (Instance::Update -> Trace(true), src/Instance.cpp:44-57) with the library's look-ahead ----------
-    single = None
-    if world == 1 and not args.no_single_frame:
-        n_calls = 64
-        pt.Reset()
-        pt.SetInstrumentation(False, False)
-        pt.SetLookahead(True)
-        for _ in range(pt.GetFramesInFlight()):
-            pt.Trace(True, 1)  # warm-up: one whole pass handed out
-        pt.ResetStats()
-        pt.DeviceSynchronize()
-        t1 = time.perf_counter()
-        for _ in range(n_calls):
-            pt.Trace(True, 1)
-        pt.DeviceSynchronize()
-        dt = time.perf_counter() - t1
-        s1 = pt.GetStats()
-        pt.SetLookahead(False)
-        pt.SetFramesInFlight(1)  # and without look-ahead, one frame per wavefront pass: what round 1's binding did
-        pt.Reset()
-        pt.Trace(True, 16)
-        pt.ResetStats()
-        t1 = time.perf_counter()
-        pt.Trace(True, 16)
-        dt0 = time.perf_counter() - t1
-        s0 = pt.GetStats()
-        single = {"calls": n_calls, "ms_per_call": round(dt * 1e3 / n_calls, 4), "Mrays_s": round(s1["rays"] / dt / 1e6, 1),
-                  "frac_of_batched": round((s1["rays"] / dt) / (total_rays / elapsed), 3),
-                  "without_lookahead_Mrays_s": round(s0["rays"] / dt0 / 1e6, 1),
-                  "note": "adypt_trace_spp(ctx, 1) per call, adypt_set_lookahead on: a call that needs untraced frames traces a whole pass of %d, the following calls only apply their running-mean step" % fif}
+        # ---- one frame per call (Instance::Update -> Trace(true), src/Instance.cpp:44-57) with the library's look-ahead ----------
+        if not args.no_single_frame:
+            n_calls = 64
+            pt.Reset()
+            pt.SetInstrumentation(False, False)
+            pt.SetLookahead(True)
+            for _ in range(pt.GetFramesInFlight()):
+                pt.Trace(True, 1)  # warm-up: one whole pass handed out
+            pt.ResetStats()
+            pt.DeviceSynchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_calls):
+                pt.Trace(True, 1)
+            pt.DeviceSynchronize()
+            dt = time.perf_counter() - t1
+            s1 = pt.GetStats()
+            pt.SetLookahead(False)
+            pt.SetFramesInFlight(1)  # and without look-ahead, one frame per wavefront pass: what round 1's binding did
+            pt.Reset()
+            pt.Trace(True, 16)
+            pt.ResetStats()
+            t1 = time.perf_counter()
+            pt.Trace(True, 16)
+            dt0 = time.perf_counter() - t1
+            s0 = pt.GetStats()
+            single = {"calls": n_calls, "ms_per_call": round(dt * 1e3 / n_calls, 4), "Mrays_s": round(s1["rays"] / dt / 1e6, 1),
+                      "frac_of_batched": round((s1["rays"] / dt) / (total_rays / elapsed), 3),
+                      "without_lookahead_Mrays_s": round(s0["rays"] / dt0 / 1e6, 1),
+                      "note": "adypt_trace_spp(ctx, 1) per call, adypt_set_lookahead on: a call that needs untraced frames traces a whole pass of %d, the following calls only apply their running-mean step" % fif}
 
-    # ---- the kernel where HBM binds, and the CPU baseline ----------------------------------------------------------------------
-    hbm = None
-    if rank == 0 and world == 1 and not args.no_hbm_block and args.scene == "sponza":
-        pt.destroy()  # frees the bench scene's queues first
-        hbm = hbm_resident_block(args, dev)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(inst, c)
+        # ---- the kernel where memory binds, and the CPU baseline ----------------------------------------------------------------------
+        if not args.no_hbm_block and args.scene == "sponza":
+            pt.destroy()  # frees the bench scene's queues first
+            hbm = hbm_resident_block(args, dev)
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(inst, c)
 
     if rank == 0:
+        values = sorted(total_rays / r["elapsed_all_ranks"] / 1e6 for r in repeats)
         value = total_rays / elapsed / 1e6
+        if multi:
+            comm = ("TEST HOOK ADYPT_MULTI_SHARED_DEVICE: %d tile shards on ONE device, device copies instead of RCCL — not a measurement" % n_gpus) if shared_hook \
+                else "native RCCL, ncclCommInitAll, %d ranks in one process" % comm_ranks
+        elif world > 1:
+            comm = "torch.distributed" if use_torch else ("host-staged TEST transport (ADYPT_COMM_TRANSPORT=host: not a measurement)" if os.environ.get("ADYPT_COMM_TRANSPORT") == "host"
+                                                         else "native RCCL, ncclCommInitRank, %d ranks, one process per GPU" % comm_ranks)
+        else:
+            comm = "none"
         out = {"metric": "Mrays/sec (primary+secondary) Sponza 1920x1080 8-bounce; % HBM-read roofline",
-               "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed * 1e3 / max(1, args.steps), 4), "higher_is_better": True, "scaling": "strong",
+               "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "strong",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%s-like procedural stand-in (%s), %d triangles, %dx%d, full wavefront path trace, maxBounce %d, tmpLifetime %d, 1 spp per step; one radiance gather per run"
+               "repeats": args.repeats, "value_min": round(values[0], 2), "value_max": round(values[-1], 2),
+               "ms_per_step_all": [round(r["elapsed_all_ranks"] * 1e3 / args.steps, 4) for r in repeats],
+               "config": {"workload": "%s-like procedural stand-in (%s), %d triangles, %dx%d, full wavefront path trace, maxBounce %d, tmpLifetime %d, 1 spp per step; one radiance gather per timed region"
                                       % (args.scene, spec.label, inst.scene.n_tris, c.width, c.height, c.max_bounce, c.tmp_lifetime),
-                          "rays_per_step": round(total_rays / max(1, args.steps)), "tile_shard": "32x32 blocks, owner (bx+by) mod N",
-                          "frames_in_flight": fif, "rays_warmup": rays_warmup, "comm": ("torch.distributed" if use_torch else ("host-staged TEST transport (ADYPT_COMM_TRANSPORT=host: not a measurement)" if os.environ.get("ADYPT_COMM_TRANSPORT") == "host" else "native RCCL")) if world > 1 else "none",
+                          "rays_per_step": round(total_rays / args.steps), "tile_shard": "32x32 blocks, owner (bx+by) mod N",
+                          "frames_in_flight": fif, "rays_warmup": rays_warmup, "comm": comm, "comm_ranks": comm_ranks,
+                          "devices": ("one process, devices %s" % ([0] * n_gpus if shared_hook else list(range(n_gpus)))) if multi else ("one process per device" if world > 1 else "device %d" % dev),
+                          "bounces_in_one_launch": bool(st.get("path_launches", 0) > 0), "timing": "median of %d repeats of [reset, %d warm-up steps, barrier, %d timed steps + gather, barrier]" % (args.repeats, args.warmup, args.steps),
                           "setup_s": round(t_setup, 2)},
-               "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_hbm_resident": hbm, "cpu_baseline": cpu, "single_frame": single,
-               "gather_ms": round(gather_ms, 3), "shade_kernels_ms": round(shade_ms, 2), "trace_kernels_ms": round(trace_ms, 2),
+               "roofline": roofline, "roofline_hbm_resident": hbm, "cpu_baseline": cpu, "primary_only": primary_only, "tmp_lifetime_1": life1, "single_frame": single,
+               "gather_ms": round(gather_ms, 3), "other_kernels_ms": round(st["shade_ms"], 2), "trace_kernels_ms": round(st["trace_ms"], 2),
                "per_rank": None if per_rank is None else {
                    "wall_ms": [round(float(v), 3) for v in per_rank[:, 0]], "trace_kernels_ms": [round(float(v), 3) for v in per_rank[:, 1]],
                    "other_kernels_ms": [round(float(v), 3) for v in per_rank[:, 2]], "gather_ms": [round(float(v), 3) for v in per_rank[:, 3]],
                    "rays": [int(v) for v in per_rank[:, 4]],
                    # share of a rank's wall time not inside a tracing kernel or the gather: launch tails show up in the kernels, host gaps here
                    "outside_kernels_frac": [round(float(1.0 - (r[1] + r[2] + r[3]) / max(r[0], 1e-9)), 3) for r in per_rank],
-                   "note": "wall = this rank's timed region (K steps + its part of the gather); rank 0's gather includes waiting for the slowest peer"},
+                   "note": "wall = the timed region of the median repeat (K steps + the gather); one process per device: each rank's own wall, rank 0's gather includes waiting "
+                           "for the slowest peer; one process for all devices: the process's wall for every device, kernel times per device"},
                "image_mean": float(image.mean()) if image is not None else None}
         print(json.dumps(out))
         sys.stdout.flush()

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ADYPT_ABI_VERSION 2
+#define ADYPT_ABI_VERSION 3
 
 enum adypt_status {
 	ADYPT_OK = 0,
@@ -93,8 +93,13 @@ typedef struct adypt_stats {
 	uint64_t bad_materials;
 	uint32_t max_stack;       /* instrumented runs only */
 	uint32_t trace_launches;
-	double trace_ms;          /* sum of HIP-event durations of the traversal kernel launches (timing enabled) */
+	double trace_ms;          /* sum of HIP-event durations of the traversal kernel launches (timing enabled): k_trace and k_path */
 	double shade_ms;          /* same for gen/shade kernels */
+	double path_ms;           /* the part of trace_ms that is k_path launches (one launch = every bounce after the first of a batch) */
+	uint32_t path_launches;   /* the part of trace_launches that is k_path launches */
+	uint32_t reserved;
+	uint64_t path_rays;       /* the part of rays / nodes_visited / tris_tested / hits / shaded that k_path launches account for */
+	uint64_t path_nodes, path_tris, path_hits, path_shaded; /* (instrumented runs only, like their totals) */
 } adypt_stats;
 
 int adypt_abi_version(void);
@@ -156,6 +161,12 @@ int adypt_get_pipeline(const adypt_ctx *ctx);
  * frames traced ahead.  adypt_set_camera, adypt_reset, adypt_trace_primary, adypt_set_sun_visibility and
  * adypt_set_frames_in_flight drop the parked frames (they are traced again, with the new state, when asked for). */
 int adypt_set_lookahead(adypt_ctx *ctx, int enabled);
+/* Bounces 1 .. maxBounce-1 of a batch of frames in ONE persistent launch (k_path: the reference's for(b < uMaxBounce) inside one
+ * dispatch, shaders/pathtracer.glsl:107, src/Tracer/OglPathTracer.cpp:60) instead of a traversal and a shade launch per bounce.  On by
+ * default (ADYPT_FUSED_BOUNCES=0 in the environment: off); used for batches of more than one frame without the sun-visibility query, the
+ * sub-batch pipeline or more than 2^26 paths.  Images are bit-identical either way.  The getter says whether the LAST batch used it. */
+int adypt_set_fused_bounces(adypt_ctx *ctx, int enabled);
+int adypt_get_fused_bounces(const adypt_ctx *ctx);
 int adypt_get_lookahead_frames(const adypt_ctx *ctx); /* frames currently parked */
 
 /* glGetTextureImage(m_result_tex, GL_RGB, GL_FLOAT) of OglPathTracer::SaveResult (OglPathTracer.cpp:203-205):
@@ -249,6 +260,8 @@ int adypt_multi_gather_radiance(adypt_multi *m, void **rgb_device);
 /* creates the RCCL communicators now (otherwise: at the first gather, and only when n_dev > 1); lets a caller — and the
  * one-GPU test — find out at start-up whether RCCL is usable */
 int adypt_multi_comm_init(adypt_multi *m);
+/* ranks of the communicator as RCCL reports them (ncclCommCount); 0 = no communicator exists (one device, or not initialised yet) */
+int adypt_multi_comm_ranks(adypt_multi *m);
 
 /* (2) One process per GPU (launchers that fork a rank per device): every rank creates its context with tile_rank = rank,
  * tile_nranks = world; rank 0 makes an id, the launcher's own channel (a file, MPI, a socket) carries its 128 bytes to the
@@ -256,6 +269,7 @@ int adypt_multi_comm_init(adypt_multi *m);
 #define ADYPT_COMM_ID_BYTES 128
 int adypt_comm_unique_id(char id[ADYPT_COMM_ID_BYTES]);
 int adypt_comm_init(adypt_ctx *ctx, const char id[ADYPT_COMM_ID_BYTES]);
+int adypt_comm_ranks(adypt_ctx *ctx); /* ncclCommCount of the context's communicator; 0 = none */
 /* the one gather: on rank 0 *rgb_device = assembled W*H*3 fp32 image in HBM (library-owned), elsewhere NULL; returns after
  * the context's stream has drained */
 int adypt_comm_gather_radiance(adypt_ctx *ctx, void **rgb_device);

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Developer tool: build a variant of the library with extra device-compile flags, for A/B runs on the GPU box (ADYPT_LIB=<path>).
-#   tools/build_variant.sh <name> [--patch adypt_amd/csrc/measure/x.patch] [-DADYPT_PATH_SLOTS=320 ...]   ->  adypt_amd/libadypt_<name>.so
+#   tools/build_variant.sh <name> [--transform adypt_amd/csrc/measure/x.py] [-DADYPT_PATH_SLOTS=320 ...]   ->  adypt_amd/libadypt_<name>.so
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 cd "$ROOT/adypt_amd/csrc"
 make -s -j8 all
 SRC=device
-if [ "$1" = "--patch" ]; then   # measurement variants live as patches under csrc/measure/: applied to a scratch copy of the device sources
+if [ "$1" = "--transform" ]; then   # measurement variants live as source transforms under csrc/measure/: applied to a scratch copy of the device sources
     SRC=.variant_$name; rm -rf $SRC; cp -r device $SRC   # (a sibling of device/: the relative includes keep working)
-    patch -s -d $SRC -p1 < "$ROOT/$2"; shift 2
+    python3 "$ROOT/$2" "$PWD/$SRC"; shift 2
 fi
 FLAGS="-std=c++17 -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-parameter -munsafe-fp-atomics -Wno-unused-result -fno-slp-vectorize -mllvm -disable-machine-licm -DADYPT_BUILD"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $SRC/tracer.hip -o build/tracer_$name.o

@@ -1,22 +1,22 @@
 #!/bin/bash
-# GPU box: rocprofv3 evidence for bench.py.  Outputs under gpurun_out/profiles/ (copy what is to be judged into profiles/).
+# GPU box: rocprofv3 evidence for bench.py.  Outputs under gpurun_out/profiles_<tag>/ (copy what is to be judged into profiles/).
 #   bash tools/collect_profiles.sh            the bench scene at the driver's command line (--steps 20 --warmup 5)
 #   bash tools/collect_profiles.sh sanmiguel  the 10 M-triangle stand-in (roofline_hbm_resident)
 # Kernel-trace/stats and every --pmc group are separate runs (gpurun refuses --pmc combined with trace domains other than
-# kernel-trace).  The kernel-trace pass runs the driver's exact command; the PMC passes add the flags that leave only the warm-up
-# and the timed frames of ONE scene in the process, so that every k_trace<false, false> launch the counters see belongs to them.
+# kernel-trace).  The kernel-trace pass runs the driver's exact command; the PMC passes add the flags that leave only ONE repeat of the
+# warm-up and the timed frames of ONE scene in the process, so that every launch of the dominant kernel the counters see belongs to them.
 set -u
 export TMPDIR=/tmp ADYPT_CACHE=${ADYPT_CACHE:-/tmp/adypt_cache}
 WHAT=${1:-bench}
 if [ "$WHAT" = "sanmiguel" ]; then
-  TAG=sanmiguel; FULL="python3 bench.py --scene sanmiguel --steps 32 --warmup 16 --no-cpu-baseline --no-single-frame"
+  TAG=sanmiguel; FULL="python3 bench.py --scene sanmiguel --steps 32 --warmup 16 --repeats 1 --no-cpu-baseline --no-single-frame --no-extra-blocks"
 else
   TAG=bench; FULL="python3 bench.py --gpus 1 --steps 20 --warmup 5"
 fi
-CMD="$FULL --no-cpu-baseline --no-hbm-block --no-single-frame"
+CMD="$FULL --no-cpu-baseline --no-hbm-block --no-single-frame --no-extra-blocks --repeats 1"
 OUT=gpurun_out/profiles_$TAG; rm -rf $OUT; mkdir -p $OUT
 $CMD > $OUT/plain_run.json 2> /dev/null   # builds the scene cache outside the profiled runs; also the un-profiled reference line
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $FULL > $OUT/stats_bench.json 2> $OUT/stats.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $FULL > $OUT/stats_bench.json 2> $OUT/stats.err
 cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 python3 tools/kernel_trace_phases.py $OUT/stats $OUT/stats_bench.json > $OUT/kernel_trace_phases.json
 for grp in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
@@ -26,4 +26,4 @@ done
 python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
 python3 tools/pmc_profile.py $OUT $OUT/pmc_FETCH_SIZE.json "rocprofv3 --pmc <group> -- $CMD" $OUT/kernel_trace_phases.json > $OUT/pmc_profile.json
 find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete
-head -8 $OUT/kernel_stats.csv | cut -c1-170; grep -A12 "^k_trace<false" $OUT/pmc_summary.txt; cat $OUT/pmc_profile.json
+head -8 $OUT/kernel_stats.csv | cut -c1-170; grep -A14 "^k_path<false\|^k_trace<false" $OUT/pmc_summary.txt; cat $OUT/pmc_profile.json

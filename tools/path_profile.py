@@ -1,5 +1,5 @@
 """Developer tool (GPU box): where the waves of k_path spend their time.  Needs the profile variant of the library:
-    tools/build_variant.sh prof --patch adypt_amd/csrc/measure/k_path_profile.patch   and   ADYPT_LIB=adypt_amd/libadypt_prof.so python tools/path_profile.py"""
+    tools/build_variant.sh prof --transform adypt_amd/csrc/measure/k_path_profile.py   and   ADYPT_LIB=adypt_amd/libadypt_prof.so python tools/path_profile.py"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

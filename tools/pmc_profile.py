@@ -1,24 +1,23 @@
-"""GPU box: per-ray PMC figures of the traversal kernel from the separate rocprofv3 --pmc passes written by
-tools/collect_profiles.sh — the file bench.py reads (profiles/r2_pmc_*.json).
+"""GPU box: per-ray PMC figures of the dominant kernel (bench.py: roofline.kernel — k_path<false> when a batch runs its bounces in one
+launch) from the separate rocprofv3 --pmc passes written by tools/collect_profiles.sh — the file bench.py reads (profiles/r4_pmc_*.json).
 
 HBM / fabric traffic, corrected as MI355X_MICROARCH.md (HBM section) prescribes for gfx950: FETCH_SIZE is reported in KB and
 counts the 128-byte fabric reads of 16-byte-per-lane loads as 64 bytes -> x 1024 x 2; WRITE_SIZE is exact -> x 1024.
 Issue: SQ_INSTS_VALU (wave-instructions) per ray; lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU).
 
 Usage: pmc_profile.py <profile dir> <bench json of one of the passes> "<command>" [kernel_trace_phases.json of the same command]
-Every pass runs the same command, so the k_trace<false, false> launches (warm-up + timed frames) trace config.rays_warmup +
-rays_per_step x steps rays in each pass."""
+Every pass runs the same command (with --repeats 1), so the kernel's launches (warm-up + timed frames) trace config.kernel_rays_warmup +
+roofline.kernel_rays rays in each pass."""
 import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from source_hash import device_source_hash
 
 root, bench_json, command = sys.argv[1], sys.argv[2], sys.argv[3]
 phases = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
-KERNEL = "k_trace<false, false>"
 
 
 def per_kernel(counter):
-    vals = []
+    vals = []  # (KERNEL is set below, before the first call)
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
@@ -27,7 +26,9 @@ def per_kernel(counter):
 
 
 bench = json.loads([l for l in open(bench_json).read().strip().splitlines() if l.startswith("{")][-1])
-rays = bench["config"]["rays_per_step"] * bench["steps"] + bench["config"]["rays_warmup"]
+block = bench.get(os.environ.get("PMC_BLOCK", "roofline")) or bench["roofline"]
+KERNEL = block["kernel"]
+rays = block["kernel_rays"] + block["kernel_rays_warmup"]
 fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
 hit, req = per_kernel("TCC_HIT_sum"), per_kernel("TCC_REQ_sum")
 insts, tcyc = per_kernel("SQ_INSTS_VALU"), per_kernel("SQ_THREAD_CYCLES_VALU")
@@ -46,7 +47,7 @@ out = {
     "correction": "gfx950: FETCH_SIZE counts 128-B fabric reads as 64 B for 16-B-per-lane loads -> x2 (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact; unit KB -> x1024",
     "traffic_bytes_per_launch": traffic / max(1, len(fetch)),
     "traffic_bytes_per_ray": traffic / max(1, rays),
-    "alg_bytes_per_ray": bench["roofline"]["alg_bytes_per_ray"],
+    "alg_bytes_per_ray": block["alg_bytes_per_ray"],
     "TCC_hit_rate": sum(hit) / max(1.0, sum(req)),
     "SQ_INSTS_VALU_per_launch": sum(insts) / max(1, len(insts)),
     "valu_insts_per_ray": sum(insts) / max(1, rays),

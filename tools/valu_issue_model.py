@@ -1,11 +1,11 @@
-"""Build profiles/r3_valu_issue_model.json (read by bench.py) from the counter calibration (tools/valu_calibrate.sh ->
+"""Build profiles/r4_valu_issue_model.json (read by bench.py) from the counter calibration (tools/valu_calibrate.sh ->
 profiles/r3_valu_calibration.json: TRUE shader cycles per wave-instruction per SIMD of one-instruction kernels) and the instruction
-mix of the traversal kernel's persistent loop (profiles/r3_k_trace_instruction_mix.json).
-    python tools/valu_issue_model.py > profiles/r3_valu_issue_model.json"""
+mix of the dominant kernel's persistent loop (profiles/r4_k_path_instruction_mix.json, tools/instruction_mix.py).
+    python tools/valu_issue_model.py > profiles/r4_valu_issue_model.json"""
 import json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cal = {r["kernel"]: r for r in json.load(open(ROOT + "/profiles/r3_valu_calibration.json"))["rows"]}
-mix = json.load(open(ROOT + "/profiles/r3_k_trace_instruction_mix.json"))
+mix = json.load(open(ROOT + "/profiles/r4_k_path_instruction_mix.json"))
 CLASSES = [
     ("normal rate (v_cvt_f32_ubyte, min/max/min3/max3, v_cmp, v_cndmask, bit-field, shifts, v_perm, ...)", "normal_rate_4_cycles", 4,
      ["k_cvt_ubyte", "k_max_f32", "k_min_f32", "k_max3_f32", "k_med3", "k_cmp", "k_cmp_sgpr", "k_cnd_sgpr", "k_bfe", "k_lshl", "k_lshl_or", "k_perm",
@@ -25,11 +25,11 @@ for name, key, architectural, kernels in CLASSES:
     ideal += share * architectural
     measured += share * m
 print(json.dumps({
-    "kernel": "k_trace<false, false>",
+    "kernel": mix["kernel"],
     "what": "shader cycles a wave-instruction holds its SIMD's vector-ALU issue, by class.  cycles_single_class_loop: profiles/r3_valu_calibration.json "
             "(GRBM_GUI_ACTIVE / 8 of kernels that issue ONE kind of instruction from 5 waves per SIMD: true cycles, no assumed clock); "
-            "cycles_architectural: the 2 / 4 / 4 / 8 those loops approach.  share: the kernel's persistent loop (profiles/r3_k_trace_instruction_mix.json; "
-            "tools/instruction_mix.py: static count over the persistent loop, refill block weighted 0.28).",
+            "cycles_architectural: the 2 / 4 / 4 / 8 those loops approach.  share: the kernel's persistent loop (profiles/r4_k_path_instruction_mix.json; "
+            "tools/instruction_mix.py: static count over the persistent loop, the blocks that do not run every trip weighted by the in-kernel profile).",
     "counter_note": "the same calibration shows SQ_ACTIVE_INST_VALU = 1 per instruction (2 per transcendental) whatever its issue time: "
                     "x 4 it is NOT a busy-cycle count (a loop of full-rate instructions reads 1.63 'busy'), so bench.py no longer builds its roof on it",
     "classes": classes,
