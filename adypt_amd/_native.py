@@ -50,7 +50,7 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("hits", C.c_uint64),
                 ("shaded", C.c_uint64), ("stack_overflows", C.c_uint64), ("bad_materials", C.c_uint64),
                 ("max_stack", C.c_uint32), ("trace_launches", C.c_uint32), ("trace_ms", C.c_double), ("shade_ms", C.c_double),
-                ("path_ms", C.c_double), ("path_launches", C.c_uint32), ("reserved", C.c_uint32), ("path_rays", C.c_uint64),
+                ("path_ms", C.c_double), ("path_launches", C.c_uint32), ("audit_errors", C.c_uint32), ("path_rays", C.c_uint64),
                 ("path_nodes", C.c_uint64), ("path_tris", C.c_uint64), ("path_hits", C.c_uint64), ("path_shaded", C.c_uint64)]
 
     def as_dict(self):

@@ -431,8 +431,9 @@ class HipPathTracer:
         N.check(fn(self._ctx, rays.ctypes.data, len(rays), hits.ctypes.data, 1 if with_stats else 0), self._ctx)
         return hits
 
-    def SetInstrumentation(self, timing: bool = False, counters: bool = False) -> None:
-        N.check(N.lib.adypt_set_instrumentation(self._ctx, (1 if timing else 0) | (2 if counters else 0)), self._ctx)
+    def SetInstrumentation(self, timing: bool = False, counters: bool = False, audit: bool = False) -> None:
+        """audit: the slot-claim audit of the ray queues (GetStats()["audit_errors"] must stay 0); a debugging aid, slow."""
+        N.check(N.lib.adypt_set_instrumentation(self._ctx, (1 if timing else 0) | (2 if counters else 0) | (4 if audit else 0)), self._ctx)
 
     def GetStats(self) -> dict:
         st = N.Stats()

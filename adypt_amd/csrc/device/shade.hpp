@@ -47,6 +47,7 @@ struct DeviceStats {                           // accumulated until adypt_reset_
 	unsigned long long wave_profile[8];          // adypt_get_wave_profile (instrumented traversal only)
 	unsigned long long clock_cycles, clock_ticks; // adypt_get_shader_clock: shader cycles / 100 MHz ticks of workgroup 0 over the traversal launches
 	unsigned long long path_rays, path_nodes, path_tris, path_hits, path_shaded; // k_path's share of rays / nodes / tris / hits / shaded
+	unsigned long long audit_errors;             // slot-claim audit (adypt_set_instrumentation flag 4): slots of an appended queue not written exactly once
 };
 
 struct RayStats { int32_t ref_idx; uint32_t nodes, tris, hash, max_depth, pad0, pad1, pad2; }; // 32 B, STATS variant

@@ -48,6 +48,32 @@ struct EventPair { hipEvent_t a, b; int kind; };
 // the runtime's dependency tracking cannot see) — round 3: cache images and counters read before / cleared after their time.
 __global__ void k_clear_counters(uint4 *p, uint32_t n16) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if(i < n16) p[i] = make_uint4(0, 0, 0, 0); }
 
+// Slot-claim audit (adypt_set_instrumentation flag 4).  append_slot (shade.hpp) hands every surviving path of a workgroup a slot of its queue
+// segment; round 3 saw a build in which whole waves claimed ONE slot (the append_slot fault).  With the audit on, the queue a kernel is
+// about to append to is filled with a poison path word, and after the kernel every slot below the segment's counter must hold a real path word, every
+// path id must appear once (a bitmap over the path ids), and every slot above the counter must still be poison.
+constexpr uint32_t kAuditPoison = 0xffffffffu;
+__global__ void k_audit_poison(float4 *out_d, size_t n, uint32_t *seen, size_t n_seen)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n) out_d[i].w = __uint_as_float(kAuditPoison);
+	if(i < n_seen) seen[i] = 0u;
+}
+__global__ void k_audit_check(const float4 *out_d, const uint32_t *count, uint32_t seg_cap, uint32_t *seen, unsigned long long *errors)
+{
+	const uint32_t seg = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= seg_cap) return;
+	const uint32_t w = __float_as_uint(out_d[(size_t)seg * seg_cap + i].w);
+	bool bad;
+	if(i < count[seg * kCursorStride])
+	{
+		const uint32_t id = w & kPathIdMask;
+		bad = w == kAuditPoison || ((atomicOr(&seen[id >> 5], 1u << (id & 31u)) >> (id & 31u)) & 1u); // never written, or a path that holds two slots
+	}
+	else bad = w != kAuditPoison;                                                                     // written beyond what the counter admits
+	if(bad) atomicAdd(errors, 1ull);
+}
+
 // out[r] = the 128-byte device record of triangle tri_indices[r]: the uTriIndices remap (traversal.glsl:253-254) applied to the data once, so that k_path
 // looks a hit's triangle up by the traversal's own reference index.  One thread per 16 bytes.
 __global__ void k_expand_references(const float4 *triangles, const int32_t *tri_indices, size_t n_refs, float4 *out)
@@ -116,6 +142,9 @@ struct adypt_ctx {
 	bool queues_ok = false;    // false after a failed (re)allocation of the queues: trace calls return ADYPT_E_STATE
 	uint32_t *d_display = nullptr; // adypt_read_display: one RGBA8 word per local pixel (allocated on first use)
 	RayStats *d_ray_stats = nullptr;
+	uint32_t *d_audit_seen = nullptr; // slot-claim audit: one bit per path id (instrumentation flag 4)
+	bool audit_selftest = false;      // ADYPT_AUDIT_SELFTEST=1: a double claim is planted before every check (tests that the detector detects)
+	size_t audit_words = 0;
 	FrameCounters *d_counters = nullptr; // [kMaxPipes]; pipe k uses d_counters + k
 	DeviceStats *d_stats = nullptr;
 	uint2 *d_spill = nullptr;  // [kMaxPipes][stack_size - lds_depth][total lanes]
@@ -570,6 +599,34 @@ int ensure_cache_slices(adypt_ctx *c, int extra)
 	return ADYPT_OK;
 }
 
+// the audit's bitmap over the path ids (one bit per queue slot is enough: ids are < capacity)
+int ensure_audit(adypt_ctx *c)
+{
+	const size_t words = ((size_t)c->alloc_slots + 31) / 32 + 1;
+	if(c->d_audit_seen && c->audit_words >= words) return ADYPT_OK;
+	HIP_TRY(c, hipDeviceSynchronize());
+	if(c->d_audit_seen) (void)hipFree(c->d_audit_seen);
+	c->d_audit_seen = nullptr; c->audit_words = 0;
+	HIP_TRY(c, hipMalloc((void **)&c->d_audit_seen, words * kMaxPipes * sizeof(uint32_t))); // one bitmap per chain: they check concurrently
+	c->audit_words = words;
+	return ADYPT_OK;
+}
+// around a kernel that appends to q's output queue: poison before, check after (both on the launch's stream)
+void audit_before(adypt_ctx *c, const QueueArgs &q, hipStream_t stream, int pipe = 0)
+{
+	if(!(c->instrumentation & 4) || !c->d_audit_seen || c->audit_words * 32 < c->alloc_slots) return;
+	const size_t n = (size_t)kNumSegments * q.seg_cap, n_seen = c->audit_words; // path ids are numbered over the whole batch, not over the chain's window
+	hipLaunchKernelGGL(k_audit_poison, dim3((unsigned)((std::max(n, n_seen) + 255) / 256)), dim3(256), 0, stream, q.out_d, n, c->d_audit_seen + (size_t)pipe * c->audit_words, n_seen);
+}
+__global__ void k_audit_plant(float4 *out_d, const uint32_t *count) { if(count[0] >= 2u) out_d[1].w = out_d[0].w; } // (self-test of the detector: two slots, one path)
+void audit_after(adypt_ctx *c, const QueueArgs &q, hipStream_t stream, int pipe = 0)
+{
+	if(!(c->instrumentation & 4) || !c->d_audit_seen || c->audit_words * 32 < c->alloc_slots) return;
+	if(c->audit_selftest) hipLaunchKernelGGL(k_audit_plant, dim3(1), dim3(1), 0, stream, q.out_d, (const uint32_t *)q.count_out);
+	hipLaunchKernelGGL(k_audit_check, dim3((q.seg_cap + 255) / 256, kNumSegments), dim3(256), 0, stream, (const float4 *)q.out_d, (const uint32_t *)q.count_out, q.seg_cap, c->d_audit_seen + (size_t)pipe * c->audit_words,
+					   &c->d_stats->audit_errors);
+}
+
 int ensure_ray_stats(adypt_ctx *c)
 {
 	if(c->d_ray_stats) return ADYPT_OK;
@@ -702,6 +759,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	if(const char *ov = getenv("ADYPT_GEN_DEAL")) c->deal_chunks = atoi(ov) != 0;
 	if(const char *ov = getenv("ADYPT_FIRST_FUSED")) c->first_fused = atoi(ov) != 0;
 	if(const char *ov = getenv("ADYPT_FUSED_BOUNCES")) c->fused_bounces = atoi(ov) != 0;
+	if(const char *ov = getenv("ADYPT_AUDIT_SELFTEST")) c->audit_selftest = atoi(ov) != 0;
 	if(const char *ov = getenv("ADYPT_SHADE_MIN")) c->shade_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_ENDGAME")) c->endgame = (uint32_t)std::max(0, std::min(1024, atoi(ov)));
@@ -840,7 +898,7 @@ void adypt_destroy(adypt_ctx *c)
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_tri_class, c->d_texels, c->d_ref_triangles, c->d_local_blocks,
 					c->d_accum, c->d_cache, c->d_cache_next, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
-					c->d_hit, c->d_ray_stats, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol, c->d_display};
+					c->d_hit, c->d_ray_stats, c->d_audit_seen, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol, c->d_display};
 	for(void *b : bufs) if(b) (void)hipFree(b);
 	for(int i = 0; i < adypt_ctx::kSobolSlots; ++i)
 	{
@@ -907,6 +965,7 @@ int adypt_set_instrumentation(adypt_ctx *c, int flags)
 {
 	if(!c) return ADYPT_E_INVALID;
 	c->instrumentation = flags;
+	if(flags & 4) { HIP_TRY(c, hipSetDevice(c->device)); int r = ensure_audit(c); if(r != ADYPT_OK) return r; }
 	if(flags & 1)
 	{
 		// a pool of event pairs for the kernel timing, created here rather than while frames are being traced
@@ -947,7 +1006,9 @@ int adypt_set_frames_in_flight(adypt_ctx *c, int n)
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	if(n == c->frames_in_flight && c->queues_ok) return ADYPT_OK;
 	drop_lookahead(c); // the parked samples live in the buffers about to be reallocated
-	return alloc_queues(c, n);
+	int r = alloc_queues(c, n);
+	if(r == ADYPT_OK && (c->instrumentation & 4)) r = ensure_audit(c);
+	return r;
 }
 
 int adypt_get_frames_in_flight(const adypt_ctx *c) { return c ? c->frames_in_flight : ADYPT_E_INVALID; }
@@ -994,7 +1055,9 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	{
 		QueueArgs q = queue_args(c, win, 1, ctr->count[0], ctr->count[0], 1); // writes queue 0
 		hipEvent_t *stop = begin_timing(c, 1, c->stream);
+		audit_before(c, q, c->stream);
 		hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 0);
+		audit_after(c, q, c->stream);
 		end_timing(stop, c->stream);
 	}
 	r = launch_trace(c, pipe, win, 0, ctr->count[0], ctr->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr, false, false, true);
@@ -1119,7 +1182,9 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			const int grid_r = (int)(kNumSegments * (pass_seg_paths(c, win, n_retrace) / kShadeThreads));
 			QueueArgs q = queue_args(c, win, 1, ctr->count[0], ctr->count[0], n_retrace);
 			hipEvent_t *stop = begin_timing(c, 1, c->stream);
+			audit_before(c, q, c->stream);
 			hipLaunchKernelGGL(k_gen_primary, dim3(grid_r), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 1);
+			audit_after(c, q, c->stream);
 			end_timing(stop, c->stream);
 			int r = launch_trace(c, pipe, win, 0, ctr->count[0], ctr->cursor[0], c->params.stack_size, stats, nullptr, false, false, true);
 			if(r != ADYPT_OK) return r;
@@ -1159,12 +1224,16 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			{
 				// camera rays + bounce 0 of every frame from the cached primary hits, the surface fetched once per pixel and tmpLifetime group
 				QueueArgs q = queue_args(c, sub[k].win, 0, pipe.counters->count[0], pipe.counters->count[1], frames_k); // out = queue 1 = bounce 1's rays
+				audit_before(c, q, pipe.stream, k);
 				hipLaunchKernelGGL(k_shade_first, dim3((unsigned)(c->n_local_px / kShadeThreads)), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, stats ? 1 : 0);
+				audit_after(c, q, pipe.stream, k);
 			}
 			else
 			{
 				QueueArgs q = queue_args(c, sub[k].win, 1, pipe.counters->count[0], pipe.counters->count[0], frames_k); // out = queue 0
+				audit_before(c, q, pipe.stream, k);
 				hipLaunchKernelGGL(k_gen_primary, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, use_cache, 1);
+				audit_after(c, q, pipe.stream, k);
 			}
 			end_timing(stop, pipe.stream);
 		}
@@ -1205,7 +1274,9 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 				memcpy(sh.dir, c->sun_dir, sizeof(sh.dir));
 				sh.enabled = c->sun_visibility;
 				hipEvent_t *stop = begin_timing(c, 1, pipe.stream);
+				audit_before(c, q, pipe.stream, k);
 				hipLaunchKernelGGL(k_shade, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, sc, q, px, sh, b, (b == 0 && !use_cache) ? 1 : 0, stats ? 1 : 0);
+				audit_after(c, q, pipe.stream, k);
 				end_timing(stop, pipe.stream);
 				if(c->sun_visibility)
 				{
@@ -1377,7 +1448,7 @@ int adypt_get_stats(adypt_ctx *c, adypt_stats *out)
 	out->rays = st.rays; out->nodes_visited = st.nodes; out->tris_tested = st.tris; out->hits = st.hits; out->shaded = st.shaded;
 	out->stack_overflows = st.overflows; out->bad_materials = st.bad_materials; out->max_stack = st.max_stack;
 	out->trace_launches = c->trace_launches; out->trace_ms = c->trace_ms; out->shade_ms = c->shade_ms;
-	out->path_ms = c->path_ms; out->path_launches = c->path_launches; out->reserved = 0;
+	out->path_ms = c->path_ms; out->path_launches = c->path_launches; out->audit_errors = (uint32_t)std::min<unsigned long long>(st.audit_errors, 0xffffffffull);
 	out->path_rays = st.path_rays; out->path_nodes = st.path_nodes; out->path_tris = st.path_tris; out->path_hits = st.path_hits; out->path_shaded = st.path_shaded;
 	return ADYPT_OK;
 }

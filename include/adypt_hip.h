@@ -97,7 +97,7 @@ typedef struct adypt_stats {
 	double shade_ms;          /* same for gen/shade kernels */
 	double path_ms;           /* the part of trace_ms that is k_path launches (one launch = every bounce after the first of a batch) */
 	uint32_t path_launches;   /* the part of trace_launches that is k_path launches */
-	uint32_t reserved;
+	uint32_t audit_errors;    /* slot-claim audit (adypt_set_instrumentation flag 4): queue slots not written exactly once; must be 0 */
 	uint64_t path_rays;       /* the part of rays / nodes_visited / tris_tested / hits / shaded that k_path launches account for */
 	uint64_t path_nodes, path_tris, path_hits, path_shaded; /* (instrumented runs only, like their totals) */
 } adypt_stats;
@@ -189,7 +189,9 @@ int adypt_trace_rays(adypt_ctx *ctx, const float *rays, int64_t n, adypt_hit *hi
  * hits[i].tri_id != -1  <=>  the GLSL function returns true; u, v, t describe that first accepted triangle. */
 int adypt_trace_rays_any(adypt_ctx *ctx, const float *rays, int64_t n, adypt_hit *hits, int with_stats);
 
-/* instrumentation: bit 0 = per-launch HIP-event timing, bit 1 = instrumented traversal (node/triangle counts) */
+/* instrumentation: bit 0 = per-launch HIP-event timing, bit 1 = instrumented traversal (node/triangle counts), bit 2 = slot-claim audit of the
+ * ray queues (every queue a kernel appends to is poisoned before the launch and checked after it: each slot below the segment's counter written
+ * exactly once, by a distinct path, nothing above it; adypt_stats::audit_errors counts violations — a debugging aid, several times slower) */
 int adypt_set_instrumentation(adypt_ctx *ctx, int flags);
 int adypt_get_stats(adypt_ctx *ctx, adypt_stats *out);
 int adypt_reset_stats(adypt_ctx *ctx);

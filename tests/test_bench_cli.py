@@ -1,0 +1,54 @@
+"""bench.py's --gpus contract: N GPUs however it is started — a launcher's WORLD_SIZE, or none (one process drives N devices through
+adypt_create_multi) — and never a silent fallback to fewer devices than asked for."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--scene", "tiny0", "--width", "192", "--height", "128", "--no-cpu-baseline", "--no-hbm-block", "--no-single-frame", "--no-extra-blocks"]
+
+
+def _bench(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
+
+
+def test_more_gpus_than_the_box_has_exits_non_zero(tmp_path):
+    """No launcher, --gpus 8: on this box (no GPU at all, or fewer than 8) the run must fail loudly — not print an n_gpus 1 line."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("the box has 8 devices")
+    r = _bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--cache", str(tmp_path)] + SMALL)
+    assert r.returncode != 0
+    assert b"never runs on fewer GPUs" in r.stderr and not r.stdout.strip()
+
+
+def test_gpus_must_match_a_launchers_world_size(tmp_path):
+    r = _bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--cache", str(tmp_path)] + SMALL, env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and b"WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.gpu
+def test_single_process_multi_device_path_on_one_card(tmp_path):
+    """The one-process path of `bench.py --gpus 3` with the three tile shards on ONE device (ADYPT_MULTI_SHARED_DEVICE, a test hook: the line
+    says so and is not a measurement): three contexts, the same image as the 1-GPU run, per-device statistics."""
+    one = _bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--repeats", "1", "--cache", str(tmp_path)] + SMALL)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    three = _bench(["--gpus", "3", "--steps", "4", "--warmup", "2", "--repeats", "2", "--cache", str(tmp_path)] + SMALL, env={"ADYPT_MULTI_SHARED_DEVICE": "1"})
+    assert three.returncode == 0, three.stderr.decode()[-2000:]
+    a, b = json.loads(one.stdout.decode().strip().splitlines()[-1]), json.loads(three.stdout.decode().strip().splitlines()[-1])
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 3
+    assert b["image_mean"] == a["image_mean"]
+    assert "not a measurement" in b["config"]["comm"]
+    pr = b["per_rank"]
+    assert len(pr["rays"]) == 3 and sum(pr["rays"]) == a["config"]["rays_per_step"] * 4 and all(r > 0 for r in pr["rays"])
+    assert b["repeats"] == 2 and len(b["ms_per_step_all"]) == 2 and b["value_min"] <= b["value"] <= b["value_max"]
+    # without the hook the same command must refuse: the box has one device
+    real = _bench(["--gpus", "3", "--steps", "4", "--warmup", "2", "--cache", str(tmp_path)] + SMALL)
+    assert real.returncode != 0 and not real.stdout.strip()

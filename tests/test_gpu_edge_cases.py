@@ -361,11 +361,9 @@ def test_texture_sampling_edges_match_oracle(tw, th, tmp_path, sobol_matrices):
     assert np.array_equal(bits(pt.ReadResult()), bits(st.accum[..., :3]))
 
 
-def test_material_zoo_matches_oracle(tmp_path, sobol_matrices):
-    """Every branch of Render's illum switch (pathtracer.glsl:144-201) on the device: diffuse, glossy above and AT the e = Ns * 0.01 > 0.3
-    threshold (falls through to diffuse), very sharp lobes, mirrors, dielectrics with Ni below / at / above 1, the values the switch does
-    not name (0, 8, 9: the ray goes straight on), materials without illum (tinyobj default 0), emitters — as patches of one floor under
-    a lamp, with a second layer below so that pass-through and refracted paths keep going."""
+def write_zoo(tmp_path):
+    """The material zoo as OBJ + MTL: every branch of Render's illum switch (pathtracer.glsl:144-201) as patches of one floor under a lamp, with
+    a second layer below so that pass-through and refracted paths keep going.  Returns (path of the .obj, the materials)."""
     mats = [("m0", "Kd 0.8 0.7 0.6\nillum 1"), ("m1", "Kd 0.5 0.5 0.5\nKs 0.4 0.4 0.4\nNs 200\nillum 2"), ("m2", "Kd 0.6 0.2 0.2\nKs 0.3 0.3 0.3\nNs 30\nillum 2"),
             ("m3", "Kd 0.2 0.6 0.2\nKs 0.5 0.5 0.5\nNs 31\nillum 2"), ("m4", "Kd 0.1 0.1 0.1\nKs 0.9 0.9 0.9\nNs 100000\nillum 2"), ("m5", "Ks 0.9 0.8 0.7\nillum 3"),
             ("m6", "Ks 1.5 1.5 1.5\nillum 4"), ("m7", "Ks 0.3 0.3 0.9\nillum 5"), ("m8", "Kd 1 1 1\nNi 1.5\nillum 6"), ("m9", "Kd 1 1 1\nNi 0.7\nillum 7"),
@@ -382,8 +380,16 @@ def test_material_zoo_matches_oracle(tmp_path, sobol_matrices):
     quad(-2, -2, 14, 8, 0.0, "base")                 # below the patches: what pass-through / refracted paths reach
     quad(1, 1, 11, 5, 5.0, "lamp", up=False)         # the lamp faces down
     (tmp_path / "zoo.obj").write_text("mtllib zoo.mtl\n" + "".join("v %g %g %g\n" % p for p in v) + "".join(f))
+    return str(tmp_path / "zoo.obj"), mats
+
+
+def test_material_zoo_matches_oracle(tmp_path, sobol_matrices):
+    """Every branch of Render's illum switch (pathtracer.glsl:144-201) on the device: diffuse, glossy above and AT the e = Ns * 0.01 > 0.3
+    threshold (falls through to diffuse), very sharp lobes, mirrors, dielectrics with Ni below / at / above 1, the values the switch does
+    not name (0, 8, 9: the ray goes straight on), materials without illum (tinyobj default 0), emitters."""
+    obj, mats = write_zoo(tmp_path)
     w, h = 96, 54
-    sc, b, pt, p = _tracer(str(tmp_path / "zoo.obj"), w, h)
+    sc, b, pt, p = _tracer(obj, w, h)
     p.max_bounce = 7
     pt.SetConfig(p)
     osc = O.Scene(b.nodes, b.tri_indices, sc.triangles, sc.materials)
