@@ -15,6 +15,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -40,7 +41,21 @@ struct HostComm {
 	                                             // by the time the next operation of the same kind and peer touches it
 	uint64_t seq_send[64] = {0}, seq_recv[64] = {0}; // per peer: how many messages so far (names the mailbox)
 	uint64_t seq_all = 0;
+	std::atomic<int> failed{0};      // a peer never arrived / a mailbox could not be made: every later call on this communicator returns an error
+	double timeout_s = 60.0;         // how long a host function waits for a peer before it gives up (ADYPT_HOST_TRANSPORT_TIMEOUT)
 };
+
+// waits for the sender to publish; false after timeout_s (the peer died between creating the mailbox and filling it)
+inline bool wait_ready(const Mailbox *m, double timeout_s)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	while(m->ready.load(std::memory_order_acquire) == 0)
+	{
+		if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+		std::this_thread::sleep_for(std::chrono::microseconds(100));
+	}
+	return true;
+}
 
 inline size_t dtype_size(ncclDataType_t t) { return t == ncclDouble || t == ncclInt64 || t == ncclUint64 ? 8 : t == ncclFloat || t == ncclInt32 || t == ncclUint32 ? 4 : t == ncclHalf ? 2 : 1; }
 inline std::string box_name(const HostComm *c, const char *kind, int src, int dst, uint64_t seq)
@@ -100,21 +115,22 @@ inline void host_send(void *p)
 		m->ready.store(o->bytes ? o->bytes : 1, std::memory_order_release);
 		munmap(m, sizeof(Mailbox) + o->bytes);
 	}
-	else fprintf(stderr, "adypt host transport: cannot create mailbox %s\n", n.c_str());
+	else { o->c->failed.store(1); fprintf(stderr, "adypt host transport: cannot create mailbox %s\n", n.c_str()); }
 	delete o;
 }
 inline void host_recv(void *p)
 {
 	Op *o = (Op *)p;
 	const std::string n = box_name(o->c, "p2p", o->peer, o->c->rank, o->seq);
-	if(Mailbox *m = map_box(n, o->bytes, false))
-	{
-		while(m->ready.load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
-		memcpy(o->staging, m->data, o->bytes);
-		munmap(m, sizeof(Mailbox) + o->bytes);
-		shm_unlink(n.c_str());
+	Mailbox *m = map_box(n, o->bytes, false, o->c->timeout_s);
+	if(m && wait_ready(m, o->c->timeout_s)) memcpy(o->staging, m->data, o->bytes);
+	else
+	{	// never copy an unwritten staging buffer to the device as if it were data: zeros, and the communicator is marked failed
+		memset(o->staging, 0, o->bytes);
+		o->c->failed.store(1);
+		fprintf(stderr, "adypt host transport: rank %d never delivered %s\n", o->peer, n.c_str());
 	}
-	else fprintf(stderr, "adypt host transport: no mailbox %s from the peer\n", n.c_str());
+	if(m) { munmap(m, sizeof(Mailbox) + o->bytes); shm_unlink(n.c_str()); }
 	delete o;
 }
 inline void host_allreduce(void *p)
@@ -127,15 +143,21 @@ inline void host_allreduce(void *p)
 		if(r == c->rank) continue;
 		const std::string n = box_name(c, "all", c->rank, r, o->seq);
 		if(Mailbox *m = map_box(n, o->bytes, true)) { memcpy(m->data, o->staging, o->bytes); m->ready.store(1, std::memory_order_release); munmap(m, sizeof(Mailbox) + o->bytes); }
+		else c->failed.store(1);
 	}
 	std::vector<unsigned char> acc((unsigned char *)o->staging, (unsigned char *)o->staging + o->bytes);
 	for(int r = 0; r < c->nranks; ++r)
 	{
 		if(r == c->rank) continue;
 		const std::string n = box_name(c, "all", r, c->rank, o->seq);
-		Mailbox *m = map_box(n, o->bytes, false);
-		if(!m) { fprintf(stderr, "adypt host transport: all-reduce: rank %d never arrived\n", r); continue; }
-		while(m->ready.load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
+		Mailbox *m = map_box(n, o->bytes, false, c->timeout_s);
+		if(!m || !wait_ready(m, c->timeout_s))
+		{
+			c->failed.store(1);
+			fprintf(stderr, "adypt host transport: all-reduce: rank %d never arrived\n", r);
+			if(m) { munmap(m, sizeof(Mailbox) + o->bytes); shm_unlink(n.c_str()); }
+			continue;
+		}
 		if(o->dt == ncclDouble)
 			for(size_t i = 0; i < o->count; ++i)
 			{
@@ -164,6 +186,7 @@ inline ncclResult_t CommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, 
 	HostComm *c = new HostComm();
 	c->name.assign(id.internal, strnlen(id.internal, NCCL_UNIQUE_ID_BYTES));
 	c->rank = rank; c->nranks = nranks;
+	if(const char *t = getenv("ADYPT_HOST_TRANSPORT_TIMEOUT")) c->timeout_s = std::max(0.1, atof(t));
 	*comm = (ncclComm_t)c;
 	return ncclSuccess;
 }
@@ -182,6 +205,7 @@ inline ncclResult_t Send(const void *buf, size_t count, ncclDataType_t dt, int p
 	HostComm *c = (HostComm *)comm;
 	const size_t bytes = count * dtype_size(dt);
 	if(peer < 0 || peer >= 64) return ncclInvalidArgument;
+	if(c->failed.load()) return ncclSystemError; // an earlier operation lost its peer: the caller sees ADYPT_E_HIP from adypt_comm_*
 	void *st = staging(c->send_buf[peer], bytes, stream);
 	if(!st) return ncclSystemError;
 	if(bytes && hipMemcpyAsync(st, buf, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return ncclUnhandledCudaError;
@@ -193,6 +217,7 @@ inline ncclResult_t Recv(void *buf, size_t count, ncclDataType_t dt, int peer, n
 	HostComm *c = (HostComm *)comm;
 	const size_t bytes = count * dtype_size(dt);
 	if(peer < 0 || peer >= 64) return ncclInvalidArgument;
+	if(c->failed.load()) return ncclSystemError;
 	void *st = staging(c->recv_buf[peer], bytes, stream);
 	if(!st) return ncclSystemError;
 	Op *o = new Op{c, st, bytes, peer, c->seq_recv[peer]++, 1, ncclSum, dt, count};
@@ -204,6 +229,7 @@ inline ncclResult_t AllReduce(const void *send, void *recv, size_t count, ncclDa
 {
 	HostComm *c = (HostComm *)comm;
 	if(dt != ncclDouble || (op != ncclSum && op != ncclMax)) return ncclInvalidArgument;
+	if(c->failed.load()) return ncclSystemError;
 	const size_t bytes = count * 8;
 	void *st = staging(c->all_buf, bytes, stream);
 	if(!st) return ncclSystemError;

@@ -43,9 +43,9 @@ thread_local std::string g_create_error;
 
 struct EventPair { hipEvent_t a, b; int kind; };
 
-// Zeroes the counters of `n` pipes.  A kernel of the context's stream rather than hipMemsetAsync: a fill of PART of an allocation was
-// observed not to be ordered against the kernels around it on this runtime (their pointers travel inside by-value structs, which
-// the runtime's dependency tracking cannot see) — round 3: cache images and counters read before / cleared after their time.
+// Zeroes the counters of `n` pipes.  A kernel rather than hipMemsetAsync: while round 3's queue corruption was being hunted (the
+// append_slot fault) the memset was suspected of not being ordered against the kernels around it and replaced; that changed the timing, not the
+// fault — the suspicion was never established.  The kernel stays because it is one launch for all pipes' counters and certainly stream-ordered.
 __global__ void k_clear_counters(uint4 *p, uint32_t n16) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if(i < n16) p[i] = make_uint4(0, 0, 0, 0); }
 
 // Slot-claim audit (adypt_set_instrumentation flag 4).  append_slot (shade.hpp) hands every surviving path of a workgroup a slot of its queue
@@ -1208,6 +1208,9 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
 			for(int k = 1; k < n_pipes; ++k) HIP_TRY(c, hipStreamWaitEvent(c->pipes[k].stream, c->fork_ev, 0));
 		}
+		// a launch that fails in the middle of the chains must not leave the other chains running unjoined: what follows on the context's stream
+		// (or the caller's next call) only synchronises c->stream, and those chains would still be writing queues, done[] and counters
+		auto abandon = [&](int code) { for(int k = 1; k < kMaxPipes; ++k) (void)hipStreamSynchronize(c->pipes[k].stream); return code; };
 		struct Sub { QueueWindow win; FrameArgs f; int grid; };
 		Sub sub[kMaxPipes];
 		for(int k = 0, frame0 = 0; k < n_pipes; ++k)
@@ -1265,7 +1268,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 				if(!(b == 0 && use_cache))
 				{
 					int r = launch_trace(c, pipe, sub[k].win, in, ctr->count[b], ctr->cursor[b], c->params.stack_size, stats, nullptr, false, false, true);
-					if(r != ADYPT_OK) return r;
+					if(r != ADYPT_OK) return abandon(r);
 				}
 				QueueArgs q = queue_args(c, sub[k].win, in, ctr->count[b], ctr->count[b + 1], sub[k].f.n_frames);
 				ShadowArgs sh;
@@ -1282,7 +1285,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 				{
 					// the escaped paths of this bounce: any-hit query towards the sun, then sun term + accumulate (pathtracer.glsl:130-135)
 					int r = launch_trace(c, pipe, sub[k].win, 0, ctr->sh_count[b], ctr->sh_cursor[b], c->params.stack_size, stats, nullptr, true, true);
-					if(r != ADYPT_OK) return r;
+					if(r != ADYPT_OK) return abandon(r);
 					stop = begin_timing(c, 1, pipe.stream);
 					hipLaunchKernelGGL(k_shadow_resolve, dim3(sub[k].grid), dim3(kShadeThreads), 0, pipe.stream, sub[k].f, q, px, sh);
 					end_timing(stop, pipe.stream);

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 	WgPool *pool = (WgPool *)(lds_stack + (size_t)(kTraceThreads / 64) * a.lds_depth * 64);
 	if(threadIdx.x == 0) { pool->range = 0ull; pool->lock = 0u; pool->dry = 0u; }
 	__syncthreads();
-	const uint32_t endgame_rays = a.endgame * a.chunk * max(1u, (gridDim.x * (kTraceThreads / 64)) / kNumSegments); // a.endgame more chunks for every wave of the segment
+	// a.endgame more chunks for every wave of the segment (64-bit product: the tuning overrides allow 1024 x 4096 x 1024 waves)
+	const uint32_t endgame_rays = (uint32_t)min((unsigned long long)a.endgame * a.chunk * max(1u, (gridDim.x * (kTraceThreads / 64)) / kNumSegments), 0xffffffffull);
 	const uint32_t total_lanes = gridDim.x * blockDim.x;
 	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
 	const int home = blockIdx.x & (kNumSegments - 1);
