@@ -61,6 +61,20 @@ rep("""			__builtin_amdgcn_s_sleep(8);
 			pf_idle += __builtin_readcyclecounter() - i0; }
 			continue;
 """)
+rep("""				if(gn == 0) break;
+				for(uint32_t i = (uint32_t)lane; i < gn; i += 64u) init_idx[have + i] = gb + i;
+""", """				if(gn == 0) break;
+				for(uint32_t i = (uint32_t)lane; i < gn; i += 64u) init_idx[have + i] = gb + i;
+""")
+# the tail: 100 MHz ticks of the launch's start, of the moment the FIRST wave finds the global queue dry, and of the last wave's end — in the
+# otherwise unused path_hits / path_nodes / path_tris counters of the un-instrumented kernel (tools/path_profile.py reads them)
+rep("""							if(gn == 0) break;
+							if(dead && dead_rank >= served""", """							if(gn == 0) { if(lane == 0) atomicCAS(&a.stats->path_nodes, 0ull, (unsigned long long)__builtin_amdgcn_s_memrealtime()); break; }
+							if(dead && dead_rank >= served""")
+rep("""	const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+""", """	const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+	if(threadIdx.x == 0) atomicCAS(&a.stats->path_hits, 0ull, clk_r0);
+""")
 rep("""#include "traverse_trip.inc"
 	}
 """, """		pf_trips += 1; pf_trip_lanes += (uint32_t)__popcll(live);
@@ -74,6 +88,7 @@ rep("""#include "traverse_trip.inc"
 		atomicAdd(&a.stats->wave_profile[5], ((unsigned long long)pf_rounds << 32) | pf_take);
 		atomicAdd(&a.stats->wave_profile[6], ((unsigned long long)pf_exchanges << 32) | (pf_lock >> 8));
 		atomicAdd(&a.stats->wave_profile[7], ((unsigned long long)pf_trips << 32) | (pf_trip_lanes >> 6));
+		atomicMax(&a.stats->path_tris, __builtin_amdgcn_s_memrealtime());
 	}
 """)
 open(p, "w").write(s)

@@ -9,6 +9,9 @@ spec = scenes.make_scene(scene, os.environ.get("ADYPT_CACHE", "/tmp/adypt_cache"
                          pt={"maxBounce": 8, "tmpLifetime": 16, "stackSize": 24, "subpixel": 8, "clamp": 4.0, "sun": [12.0, 11.0, 10.0]})
 inst = api.Instance(); assert inst.InitializeFromFile(spec.config_path, shift_seed=12345, tile_rank=0, tile_nranks=nr)
 p = inst.m_path_tracer; p.SetInstrumentation(timing=True); p.Trace(True, 5); p.DeviceSynchronize(); p.ResetStats()
+# (the profile variant keeps three 100 MHz timestamps in otherwise unused counters: start / first wave that finds the queue dry (atomicMin) / last end)
+import ctypes
+from adypt_amd import _native as N
 t0 = time.perf_counter(); p.Trace(True, fr); dt = time.perf_counter() - t0
 s = p.GetStats(); w = list(p.GetWaveProfile().values())
 total = w[0]
@@ -20,4 +23,6 @@ print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("A
                   "shading_rounds": hi(w[5]), "paths_per_round": round(lo(w[5]) / max(1, hi(w[5])), 2), "exchanges": hi(w[6]), "trips": hi(w[7]),
                   "lanes_per_trip": round(lo(w[7]) * 64 / max(1, hi(w[7])), 2), "wanted_to_shade_but_busy": w[4] >> 40,
                   "avg_to_shade_backlog_at_exchange": round((w[4] & ((1 << 40) - 1)) / max(1, hi(w[6])), 1),
-                  "avg_round_cycles": round(w[2] / max(1, hi(w[5]))), "avg_exchange_cycles_excl_shading": round((w[1] - w[2]) / max(1, hi(w[6]))), "rays": int(s["rays"])}))
+                  "avg_round_cycles": round(w[2] / max(1, hi(w[5]))), "avg_exchange_cycles_excl_shading": round((w[1] - w[2]) / max(1, hi(w[6]))), "rays": int(s["rays"]),
+                  "launch_us": round((s["path_tris"] - s["path_hits"]) / 100.0, 1) if s["path_hits"] else None,
+                  "tail_us_after_the_queue_ran_dry": round((s["path_tris"] - s["path_nodes"]) / 100.0, 1) if s["path_nodes"] else None}))
