@@ -52,3 +52,26 @@ def test_single_process_multi_device_path_on_one_card(tmp_path):
     # without the hook the same command must refuse: the box has one device
     real = _bench(["--gpus", "3", "--steps", "4", "--warmup", "2", "--cache", str(tmp_path)] + SMALL)
     assert real.returncode != 0 and not real.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_process_per_gpu_path_of_the_bench_with_two_ranks_on_one_card(tmp_path):
+    """What the driver's launcher starts — one bench.py process per rank, RANK / WORLD_SIZE in the environment — with the two ranks sharing the one
+    card through the host-staged TEST transport (RCCL refuses two ranks on one device): the repeats, the barriers, the gather and the per-rank
+    table run with world 2, and the image is the 1-GPU image."""
+    one = _bench(["--gpus", "1", "--steps", "4", "--warmup", "2", "--repeats", "1", "--cache", str(tmp_path / "one")] + SMALL)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    env = {"WORLD_SIZE": "2", "ADYPT_COMM_TRANSPORT": "host", "ADYPT_BENCH_DEVICE": "0", "MASTER_PORT": str(20000 + os.getpid() % 20000), "ADYPT_RUN_ID": "bench%d" % os.getpid()}
+    procs = []
+    for r in range(2):
+        e = dict(os.environ)
+        e.update(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--repeats", "3", "--cache", str(tmp_path / "two")] + SMALL,
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], (outs[0][1].decode()[-1500:], outs[1][1].decode()[-1500:])
+    a, b = json.loads(one.stdout.decode().strip().splitlines()[-1]), json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert not outs[1][0].strip()  # only rank 0 prints
+    assert b["n_gpus"] == 2 and b["image_mean"] == a["image_mean"] and "not a measurement" in b["config"]["comm"]
+    assert len(b["per_rank"]["rays"]) == 2 and sum(b["per_rank"]["rays"]) == a["config"]["rays_per_step"] * 4
+    assert b["repeats"] == 3 and len(b["ms_per_step_all"]) == 3
