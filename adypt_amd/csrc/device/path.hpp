@@ -95,9 +95,22 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 #define ADYPT_PATH_WAVES 6  // waves per SIMD the register allocation is held to (6: <= 80 VGPRs, like k_trace)
 #endif
 
-template <bool STATS>
-__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathArgs a, FrameArgs f, SceneArgs sc, PixelArgs px, int count_stats)
+struct PathKernArgs { PathArgs a; FrameArgs f; SceneArgs sc; PixelArgs px; int count_stats; }; // the kernel's one parameter: offset 0 of the kernarg segment
+__device__ __forceinline__ const PathKernArgs &rare_args()
 {
+	unsigned long long k = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(k)); // (not hoisted out of the block that calls this, not merged with the by-value parameter)
+	return *(const PathKernArgs *)(const __attribute__((address_space(4))) PathKernArgs *)k;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathKernArgs K)
+{
+	// The kernel's arguments are read in two ways.  What the traversal loop and the prologue need comes from the by-value parameter (the compiler
+	// keeps those fields in SGPRs).  What only the shading round and the epilogue need — two dozen pointers and scalars — is loaded where it is
+	// used, through the dispatch's kernarg segment behind a value the compiler cannot see through (rare_args()): held in SGPRs across the
+	// persistent loop they would push the loop's own scalars into spills.
+	const PathArgs &a = K.a;
 	constexpr bool ANY = false;
 	constexpr bool kUniformTmin = true; // every ray of the pass has the pass's tmin
 	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64] | path table [kTabFields][kPathSlots] | parking [kParkDwords][64] | to-shade, to-trace rings | PathCtl
@@ -109,7 +122,18 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	uint16_t *to_shade = (uint16_t *)(park + kParkDwords * 64), *to_trace = to_shade + kPathSlots;
 	PathCtl *ctl = (PathCtl *)(to_trace + kPathSlots);
 	const uint32_t total_lanes = gridDim.x * blockDim.x;
-	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+	// the lane's column of the HBM spill array, addressed where it is used (stack entries beyond the LDS depth): as a pointer it would hold two
+	// registers through the whole loop for the sake of a rare branch
+	struct SpillColumn {
+		uint2 *base;
+		__device__ __forceinline__ uint2 &operator[](size_t i) const
+		{
+			uint32_t t = threadIdx.x;
+			asm volatile("" : "+v"(t));
+			return base[i + (size_t)(blockIdx.x * (uint32_t)kTraceThreads + t)];
+		}
+	};
+	const SpillColumn my_spill{a.spill};
 	const int home = blockIdx.x & (kNumSegments - 1);
 	const float tmin = a.tmin;
 
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		if(__builtin_amdgcn_readlane((int)seg_len_lanes, sgm) == 0) seg_done |= 1u << sgm;
 
 	// a path of the global queue moves into table slot `slot`
-	auto load_path = [&](uint32_t idx, uint32_t slot) {
+	auto load_path = [&](const PathArgs &a, uint32_t idx, uint32_t slot) {
 		const F3 o = ld3(a.in_o, idx);
 		const float4 d4 = a.in_d[idx];
 		const F3 c3 = ld3(a.in_col, idx);
@@ -156,8 +180,8 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		if(threadIdx.x < have) i0 = init_idx[threadIdx.x];
 		if(threadIdx.x + kTraceThreads < have) i1 = init_idx[threadIdx.x + kTraceThreads];
 		__syncthreads(); // the stack area is free again
-		if(threadIdx.x < have) load_path(i0, threadIdx.x);
-		if(threadIdx.x + kTraceThreads < have) { load_path(i1, threadIdx.x + kTraceThreads); to_trace[threadIdx.x] = (uint16_t)(threadIdx.x + kTraceThreads); }
+		if(threadIdx.x < have) load_path(a, i0, threadIdx.x);
+		if(threadIdx.x + kTraceThreads < have) { load_path(a, i1, threadIdx.x + kTraceThreads); to_trace[threadIdx.x] = (uint16_t)(threadIdx.x + kTraceThreads); }
 		__syncthreads(); // slots beyond the lanes are on the to-trace list before any wave looks at it
 	}
 
@@ -277,6 +301,8 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				if(do_shade)
 				{
 					asm volatile("; ADYPT_MARK shade_begin");
+					const PathKernArgs &R = rare_args();
+					const PathArgs &a = R.a; const FrameArgs &f = R.f; const SceneArgs &sc = R.sc; const PixelArgs &px = R.px; const int count_stats = R.count_stats;
 					// ---------------- one iteration of Render()'s loop (pathtracer.glsl:107-202) for `take` paths, one per lane ----------------
 					// The wave's own rays wait.  What of their state is not a function of the path table is parked in LDS for the round: the shading
 					// code then has the registers the traversal loop lives in, and the loop itself stays register-allocated as in k_trace.
@@ -384,7 +410,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 							served += gn;
 						}
 					}
-					if(repl) load_path(idx, sslot);
+					if(repl) load_path(a, idx, sslot);
 					// every global store of this round (finished samples, parked radiance) has left before another wave of the workgroup can
 					// shade these paths again (same CU, same L1: no more is needed inside a workgroup)
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -430,18 +456,20 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	}
 
 	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------
+	const PathKernArgs &E = rare_args();
+	const PixelArgs &px = E.px;
 	if(lane == 0) { atomicAdd(&ctl->rays, wave_rays); if(wave_shaded) atomicAdd(&ctl->shaded, wave_shaded); if(wave_bad) atomicAdd(&px.stats->bad_materials, (unsigned long long)wave_bad); }
-	if(any_overflow) atomicAdd(&a.stats->overflows, 1ull);
+	if(any_overflow) atomicAdd(&E.a.stats->overflows, 1ull);
 	__syncthreads();
 	if(threadIdx.x == 0)
 	{
-		atomicAdd(&a.stats->rays, (unsigned long long)ctl->rays);
-		atomicAdd(&a.stats->path_rays, (unsigned long long)ctl->rays);
+		atomicAdd(&E.a.stats->rays, (unsigned long long)ctl->rays);
+		atomicAdd(&E.a.stats->path_rays, (unsigned long long)ctl->rays);
 		if(ctl->shaded) { atomicAdd(&px.stats->shaded, (unsigned long long)ctl->shaded); atomicAdd(&px.stats->path_shaded, (unsigned long long)ctl->shaded); }
 		if(blockIdx.x == 0)
 		{
-			atomicAdd(&a.stats->clock_cycles, __builtin_readcyclecounter() - clk_c0);
-			atomicAdd(&a.stats->clock_ticks, __builtin_amdgcn_s_memrealtime() - clk_r0);
+			atomicAdd(&E.a.stats->clock_cycles, __builtin_readcyclecounter() - clk_c0);
+			atomicAdd(&E.a.stats->clock_ticks, __builtin_amdgcn_s_memrealtime() - clk_r0);
 		}
 	}
 	if(STATS)
@@ -456,11 +484,11 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		}
 		if(lane == 0)
 		{
-			for(int i = 0; i < 8; ++i) atomicAdd(&a.stats->wave_profile[i], wp[i]);
-			atomicAdd(&a.stats->nodes, st_nodes); atomicAdd(&a.stats->path_nodes, st_nodes);
-			atomicAdd(&a.stats->tris, st_tris); atomicAdd(&a.stats->path_tris, st_tris);
-			atomicAdd(&a.stats->hits, st_hits); atomicAdd(&a.stats->path_hits, st_hits);
-			atomicMax(&a.stats->max_stack, st_maxdepth);
+			for(int i = 0; i < 8; ++i) atomicAdd(&E.a.stats->wave_profile[i], wp[i]);
+			atomicAdd(&E.a.stats->nodes, st_nodes); atomicAdd(&E.a.stats->path_nodes, st_nodes);
+			atomicAdd(&E.a.stats->tris, st_tris); atomicAdd(&E.a.stats->path_tris, st_tris);
+			atomicAdd(&E.a.stats->hits, st_hits); atomicAdd(&E.a.stats->path_hits, st_hits);
+			atomicMax(&E.a.stats->max_stack, st_maxdepth);
 		}
 	}
 }

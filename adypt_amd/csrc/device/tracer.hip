@@ -385,8 +385,9 @@ int launch_path(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int pari
 	a.refill_min = c->refill_min; a.shade_min = c->shade_min;
 	a.b0 = b0; a.tmin = c->params.ray_tmin;
 	hipEvent_t *stop = begin_timing(c, 2, pipe.stream);
-	if(stats) hipLaunchKernelGGL(k_path<true>, dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, a, f, sc, px, 1);
-	else hipLaunchKernelGGL(k_path<false>, dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, a, f, sc, px, 0);
+	const PathKernArgs K{a, f, sc, px, stats ? 1 : 0};
+	if(stats) hipLaunchKernelGGL(k_path<true>, dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, K);
+	else hipLaunchKernelGGL(k_path<false>, dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, K);
 	end_timing(stop, pipe.stream);
 	HIP_TRY(c, hipGetLastError());
 	return ADYPT_OK;

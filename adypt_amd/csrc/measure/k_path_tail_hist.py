@@ -18,15 +18,16 @@ rep("""							if(gn == 0) break;
 							if(dead && dead_rank >= served""")
 rep("""	if(threadIdx.x == 0)
 	{
-		atomicAdd(&a.stats->rays, (unsigned long long)ctl->rays);
+		atomicAdd(&E.a.stats->rays, (unsigned long long)ctl->rays);
 """, """	if(threadIdx.x == 0)
 	{
 		{
-			const unsigned long long dry = __hip_atomic_load(&a.stats->path_nodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), now = __builtin_amdgcn_s_memrealtime();
+			const unsigned long long dry = __hip_atomic_load(&E.a.stats->path_nodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), now = __builtin_amdgcn_s_memrealtime();
 			const unsigned long long d = dry && now > dry ? (now - dry) / 10000ull : 0ull; // 100 MHz ticks -> 100 us buckets
 			const uint32_t b = (uint32_t)(d > 15ull ? 15ull : d);
-			atomicAdd(&a.stats->wave_profile[b >> 1], 1ull << ((b & 1u) * 32u));
+			atomicAdd(&E.a.stats->wave_profile[b >> 1], 1ull << ((b & 1u) * 32u));
+			atomicAdd(&E.a.stats->path_tris, dry && now > dry ? now - dry : 0ull); // sum of the end times (ticks): the mean
 		}
-		atomicAdd(&a.stats->rays, (unsigned long long)ctl->rays);
+		atomicAdd(&E.a.stats->rays, (unsigned long long)ctl->rays);
 """)
 open(p, "w").write(s)

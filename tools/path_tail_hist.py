@@ -15,4 +15,4 @@ hist = []
 for v in w:
     hist += [v & 0xffffffff, v >> 32]
 print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("ADYPT_") and k not in ("ADYPT_RCCL_LIB", "ADYPT_LIB")}, "nranks": nr, "k_path_ms": round(s["path_ms"], 3),
-                  "workgroups_ending_per_100us_after_the_queue_ran_dry": hist}))
+                  "workgroups_ending_per_100us_after_the_queue_ran_dry": hist, "mean_end_us_after_dry": round(s["path_tris"] / max(1, sum(hist)) / 100.0, 1)}))
