@@ -121,19 +121,8 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	uint32_t *park = tab + kTabFields * kPathSlots;
 	uint16_t *to_shade = (uint16_t *)(park + kParkDwords * 64), *to_trace = to_shade + kPathSlots;
 	PathCtl *ctl = (PathCtl *)(to_trace + kPathSlots);
-	const uint32_t total_lanes = gridDim.x * blockDim.x;
-	// the lane's column of the HBM spill array, addressed where it is used (stack entries beyond the LDS depth): as a pointer it would hold two
-	// registers through the whole loop for the sake of a rare branch
-	struct SpillColumn {
-		uint2 *base;
-		__device__ __forceinline__ uint2 &operator[](size_t i) const
-		{
-			uint32_t t = threadIdx.x;
-			asm volatile("" : "+v"(t));
-			return base[i + (size_t)(blockIdx.x * (uint32_t)kTraceThreads + t)];
-		}
-	};
-	const SpillColumn my_spill{a.spill};
+	const uint32_t total_lanes = gridDim.x * (uint32_t)kTraceThreads;
+	const SpillColumn<true> my_spill(a.spill); // (addressed where it is used: traverse.hpp)
 	const int home = blockIdx.x & (kNumSegments - 1);
 	const float tmin = a.tmin;
 

@@ -287,21 +287,6 @@ __global__ __launch_bounds__(kShadeThreads) void k_gen_primary(FrameArgs f, Scen
 	if(use_cache) { const float4 h = cache_of_group(f, px, frame_group(f, frame))[L]; st3(q.hit, slot, h.x, h.y, h.z); }
 }
 
-// Batches of several frames: the frames that re-trace their primary rays (spp % tmpLife == 0) run a primary-only
-// pass first and park the hits in the cache image of their tmpLifetime group (pathtracer.glsl:121-127); every frame
-// of the batch then starts from the cache of its group.
-__global__ __launch_bounds__(kShadeThreads) void k_store_cache(FrameArgs f, QueueArgs q, PixelArgs px)
-{
-	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
-	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
-	if(local >= q.count_in[seg * kCursorStride]) return;
-	const uint32_t slot = seg * q.seg_cap + local;
-	const F3 h = ld3(q.hit, slot);
-	const uint32_t pi = __float_as_uint(q.ray_d[slot].w) & kPathIdMask; // path id: (batch frame, local pixel)
-	const int frame = (int)(pi / (uint32_t)f.n_local_px), L = (int)(pi % (uint32_t)f.n_local_px);
-	cache_of_group(f, px, frame_group(f, frame))[L] = make_float4(h.x, h.y, h.z, 0.0f);
-}
-
 // Applies finished samples of a batch to the running mean in frame order (pathtracer.glsl:224-226): batch frames
 // [first, first + count); f.spp = index of the batch's first frame.  The whole batch at once, or — when the caller asks for
 // one frame per call and the batch was traced ahead (adypt_set_lookahead) — a few frames per call.
@@ -741,21 +726,17 @@ __global__ __launch_bounds__(kShadeThreads) void k_shadow_resolve(FrameArgs f, Q
 	finish_path(f, px, pi, L, ret);
 }
 
-// primaryray.glsl main (:46-94): colour the primary hit by viewer type; also records the hit in the cache image
-__global__ __launch_bounds__(kShadeThreads) void k_viewer(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int viewer_type)
+// primaryray.glsl main (:46-94): colour the primary hit by viewer type.  The hit is in the cache image already (k_trace_camera wrote it
+// there, primaryray.glsl:93): one thread per local pixel, no queue.
+__global__ __launch_bounds__(kShadeThreads) void k_viewer(FrameArgs f, SceneArgs sc, PixelArgs px, int viewer_type)
 {
 	ADYPT_VGPR_SLACK("v32");
-	const uint32_t seg = blockIdx.x & (kNumSegments - 1), chunk = blockIdx.x >> 3;
-	const uint32_t n_in = q.count_in[seg * kCursorStride];
-	const uint32_t local = chunk * kShadeThreads + threadIdx.x;
-	if(local >= n_in) return;
-	const uint32_t slot = seg * q.seg_cap + local;
-	const float4 rd = q.ray_d[slot];
-	const F3 h = ld3(q.hit, slot);
-	const int L = __float_as_int(rd.w);
+	const int L = (int)(blockIdx.x * kShadeThreads + threadIdx.x);
+	int x = 0, y = 0;
+	if(L >= f.n_local_px || !local_pixel_xy(f, sc.local_blocks, L, &x, &y)) return;
+	const float4 h = px.cache[L];
 	const int tri_idx = __float_as_int(h.x);
 	const float u = h.y, v = h.z;
-	px.cache[L] = make_float4(h.x, u, v, 0.0f);
 	F3 color = f3(0, 0, 0);
 	if(tri_idx != -1)
 	{

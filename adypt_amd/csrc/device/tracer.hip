@@ -110,6 +110,7 @@ struct adypt_ctx {
 	int n_tex = 0;
 	int width = 0, height = 0, blocks_x = 0, blocks_y = 0, rank = 0, nranks = 1;
 	int n_local_blocks = 0, n_local_px = 0;
+	int64_t n_image_px = 0; // pixels of the owned blocks that lie inside the image (= camera rays per frame)
 	std::vector<int32_t> local_blocks;
 
 	// per local pixel
@@ -482,6 +483,33 @@ inline QueueWindow pipe_window(const adypt_ctx *c, int k, int n_pipes)
 	return QueueWindow{(size_t)k * (size_t)cap * kNumSegments, cap};
 }
 
+// Camera rays of a pass -> traversal -> cache images, one launch (k_trace_camera).  `f` names the frames of the pass (n_frames, frame_first,
+// frame_stride); the cursors of `ctr` must be clear.
+int launch_trace_camera(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, FrameCounters *ctr, const FrameArgs &f, const PixelArgs &px, int bias_mode, bool stats)
+{
+	TraceCameraArgs K;
+	memset(&K, 0, sizeof(K));
+	TraceArgs &a = K.a;
+	a.nodes = (const uint4 *)c->d_nodes; a.woop = (const float4 *)c->d_woop; a.tri_indices = (const int32_t *)c->d_tri_indices;
+	a.packed = 1u; a.tmin = c->params.ray_tmin;
+	a.cursor = ctr->cursor[0];
+	a.spill = pipe.spill; a.stats = c->d_stats;
+	K.seg_paths = pass_seg_paths(c, win, f.n_frames);
+	K.seg_shift = 8;
+	while((1u << K.seg_shift) < K.seg_paths) ++K.seg_shift;
+	a.seg_cap = 1u << K.seg_shift; // (positions are numbers: nothing is stored at them)
+	K.rays = (unsigned long long)c->n_image_px * (unsigned long long)f.n_frames;
+	a.refill_min = c->refill_min_primary; a.chunk = c->chunk; a.bite = c->bite; a.endgame = c->endgame;
+	a.stack_size = c->params.stack_size; a.lds_depth = c->lds_depth;
+	K.f = f; K.local_blocks = (const int32_t *)c->d_local_blocks; K.px = px; K.bias_mode = bias_mode;
+	hipEvent_t *stop = begin_timing(c, 0, pipe.stream);
+	if(stats) hipLaunchKernelGGL(k_trace_camera<true>, dim3(c->trace_blocks), dim3(kTraceThreads), c->lds_bytes, pipe.stream, K);
+	else hipLaunchKernelGGL(k_trace_camera<false>, dim3(c->trace_blocks), dim3(kTraceThreads), c->lds_bytes, pipe.stream, K);
+	end_timing(stop, pipe.stream);
+	HIP_TRY(c, hipGetLastError());
+	return ADYPT_OK;
+}
+
 QueueArgs queue_args(adypt_ctx *c, const QueueWindow &win, int in, const uint32_t *count_in, uint32_t *count_out, int frames = 0)
 {
 	QueueArgs q;
@@ -777,6 +805,12 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	c->local_blocks = owned_blocks(c->width, c->height, c->rank, c->nranks);
 	c->n_local_blocks = (int)c->local_blocks.size();
 	c->n_local_px = c->n_local_blocks * kBlockPixels;
+	c->n_image_px = 0;
+	for(int32_t blk : c->local_blocks)
+	{
+		const int bx = blk % c->blocks_x, by = blk / c->blocks_x;
+		c->n_image_px += (int64_t)std::min(kBlockDim, c->width - bx * kBlockDim) * (int64_t)std::min(kBlockDim, c->height - by * kBlockDim);
+	}
 
 	TRY_CREATE(upload(c, &c->d_nodes, (const uint8_t *)d->nodes, (size_t)d->n_nodes * 80));
 	TRY_CREATE(upload(c, &c->d_tri_indices, d->tri_indices, (size_t)d->n_refs));
@@ -1057,21 +1091,12 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	const QueueWindow win = full_window(c);
 	FrameCounters *ctr = pipe.counters;
 	clear_counters(c, ctr, 1, c->stream);
-	const int grid_c = (int)(kNumSegments * (pass_seg_paths(c, win, 1) / kShadeThreads)); // kNumSegments x chunks per segment of a one-frame pass
-	{
-		QueueArgs q = queue_args(c, win, 1, ctr->count[0], ctr->count[0], 1); // writes queue 0
-		hipEvent_t *stop = begin_timing(c, 1, c->stream);
-		audit_before(c, q, c->stream);
-		hipLaunchKernelGGL(k_gen_primary, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 0);
-		audit_after(c, q, c->stream);
-		end_timing(stop, c->stream);
-	}
-	r = launch_trace(c, pipe, win, 0, ctr->count[0], ctr->cursor[0], c->params.stack_size, (c->instrumentation & 2) != 0, nullptr, false, false, true, true);
+	// camera rays -> traversal -> cache image in one launch, then the viewer's colour per pixel (primaryray.glsl:46-94)
+	r = launch_trace_camera(c, pipe, win, ctr, f, px, 0, (c->instrumentation & 2) != 0);
 	if(r != ADYPT_OK) return r;
 	{
-		QueueArgs q = queue_args(c, win, 0, ctr->count[0], ctr->count[1], 1);
 		hipEvent_t *stop = begin_timing(c, 1, c->stream);
-		hipLaunchKernelGGL(k_viewer, dim3(grid_c), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, viewer_type);
+		hipLaunchKernelGGL(k_viewer, dim3((unsigned)(c->n_local_px / kShadeThreads)), dim3(kShadeThreads), 0, c->stream, f, sc, px, viewer_type);
 		end_timing(stop, c->stream);
 	}
 	HIP_TRY(c, hipGetLastError());
@@ -1185,19 +1210,8 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			FrameCounters *ctr = pipe.counters;
 			clear_counters(c, ctr, 1, c->stream);
 			f.n_frames = n_retrace; f.frame_first = first_retrace; f.frame_stride = life;
-			const int grid_r = (int)(kNumSegments * (pass_seg_paths(c, win, n_retrace) / kShadeThreads));
-			QueueArgs q = queue_args(c, win, 1, ctr->count[0], ctr->count[0], n_retrace);
-			hipEvent_t *stop = begin_timing(c, 1, c->stream);
-			audit_before(c, q, c->stream);
-			hipLaunchKernelGGL(k_gen_primary, dim3(grid_r), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, 0, 1);
-			audit_after(c, q, c->stream);
-			end_timing(stop, c->stream);
-			int r = launch_trace(c, pipe, win, 0, ctr->count[0], ctr->cursor[0], c->params.stack_size, stats, nullptr, false, false, true, true);
+			int r = launch_trace_camera(c, pipe, win, ctr, f, px, 1, stats);
 			if(r != ADYPT_OK) return r;
-			QueueArgs q2 = queue_args(c, win, 0, ctr->count[0], ctr->count[1], n_retrace);
-			stop = begin_timing(c, 1, c->stream);
-			hipLaunchKernelGGL(k_store_cache, dim3(grid_r), dim3(kShadeThreads), 0, c->stream, f, q2, px);
-			end_timing(stop, c->stream);
 			f.frame_stride = 1;
 		}
 		// The main pass, cut into n_pipes sub-batches of consecutive frames; sub-batch k = the chain gen -> [trace -> shade] x

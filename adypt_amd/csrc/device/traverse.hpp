@@ -31,6 +31,26 @@ constexpr int kEndgame = 4;    // default: the end of a launch = fewer than this
 struct WgPool { unsigned long long range; uint32_t lock, dry; }; // range = (end << 32) | next: reserved, not yet handed to a wave
 constexpr int kNodeUint4 = 5;  // the 80-byte WideBVHNode, verbatim (src/BVH/WideBVH.hpp:13-26)
 
+// The lane's column of the HBM spill array (stack entries beyond the LDS depth): my_spill[depth x lanes of the launch].  AT_USE: the column's
+// address is computed where it is used, behind a value the compiler cannot hoist — as a pointer it holds two VGPRs through the whole persistent
+// loop for the sake of a rare branch (k_path, k_trace_camera: the registers are needed; k_trace keeps the pointer, it has them).
+template <bool AT_USE> struct SpillColumn;
+template <> struct SpillColumn<false> {
+	uint2 *column;
+	__device__ __forceinline__ explicit SpillColumn(uint2 *base) : column(base + (blockIdx.x * (uint32_t)kTraceThreads + threadIdx.x)) {}
+	__device__ __forceinline__ uint2 &operator[](size_t i) const { return column[i]; }
+};
+template <> struct SpillColumn<true> {
+	uint2 *base;
+	__device__ __forceinline__ explicit SpillColumn(uint2 *b) : base(b) {}
+	__device__ __forceinline__ uint2 &operator[](size_t i) const
+	{
+		uint32_t t = threadIdx.x;
+		asm volatile("" : "+v"(t));
+		return base[i + (size_t)(blockIdx.x * (uint32_t)kTraceThreads + t)];
+	}
+};
+
 // Reserve up to `want` consecutive rays: first from the segment of "our" XCD (blockIdx & 7 groups the workgroups
 // that share an L2 under the observed round-robin dispatch — a speed hint only), then steal from the others.
 // One device atomic and nothing else per reservation: the segment lengths are read once per wave (lane s of
@@ -63,14 +83,46 @@ __device__ __forceinline__ uint32_t fetch_rays(uint32_t seg_len_lanes, uint32_t 
 
 // ANY = the any-hit overload of the reference (traversal.glsl:257-494, never called by its shaders — SURVEY.md §8 f1):
 // identical traversal, the ray ends at the FIRST accepted triangle in traversal order.
-template <bool STATS, bool ANY = false>
-__global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_trace(TraceArgs a) // hot variant: <= 80 VGPRs, 6 waves per SIMD
+//
+// CAMERA = the rays are the camera rays of a pass (primaryray.glsl:23-44 Camera(), pathtracer.glsl:51-71 with the sub-pixel bias): nothing is read
+// from a ray queue and no hit goes to one — the lane computes its ray from the queue POSITION it reserved (the position -> path mapping of
+// k_gen_primary, so the XCD segments hold what they held) and writes the finished hit into the cache image of its pixel (what k_gen_primary ->
+// k_trace -> k_viewer / k_store_cache did in three launches and 2 x 40 bytes of queue traffic per ray).
+struct TraceCameraArgs {            // the ONE parameter of k_trace_camera (offset 0 of the kernarg segment: camera_args())
+	TraceArgs a;                    //   a.count, a.ray_o, a.ray_d, a.hit are unused; a.seg_cap = 1 << seg_shift (positions are numbers, not memory)
+	uint32_t seg_paths;             //   queue positions per segment (QueueArgs::seg_paths of the pass; a multiple of 256)
+	uint32_t seg_shift;             //   position = segment << seg_shift | place in the segment
+	unsigned long long rays;        //   camera rays of the pass (in-image pixels of the owned blocks x frames)
+	FrameArgs f;                    //   n_frames / frame_first / frame_stride: the frames of the pass
+	const int32_t *local_blocks;
+	PixelArgs px;                   //   cache, cache_next: where the hits go
+	int32_t bias_mode;              //   0: Camera() of primaryray.glsl; 1: Camera(SubPixel()) of pathtracer.glsl
+};
+// read where they are used (the refill block), not held in SGPRs across the persistent loop (see k_path's rare_args())
+__device__ __forceinline__ const TraceCameraArgs &camera_args()
 {
-	constexpr bool kUniformTmin = false; // ray batches handed in by the caller carry a tmin per ray
+	unsigned long long k = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(k));
+	return *(const TraceCameraArgs *)(const __attribute__((address_space(4))) TraceCameraArgs *)k;
+}
+// The hit of a camera ray -> cache image of the frame's tmpLifetime group (pathtracer.glsl:121-127, primaryray.glsl:93).  `where` = group x
+// local pixels + local pixel: group 0 is the cache image, the later groups of a batch follow in cache_next.
+__device__ __forceinline__ void camera_store_hit(const TraceCameraArgs &R, uint32_t where, int32_t tri, float u, float v)
+{
+	const uint32_t n = (uint32_t)R.f.n_local_px;
+	float4 *dst = where < n ? R.px.cache + where : R.px.cache_next + (where - n);
+	*dst = make_float4(__int_as_float(tri), u, v, 0.0f);
+}
+
+template <bool STATS, bool ANY, bool CAMERA>
+__device__ __forceinline__ void trace_loop(const TraceArgs a)
+{
+	constexpr bool kUniformTmin = CAMERA; // ray batches handed in by the caller carry a tmin per ray; camera rays the pass's
 	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64], then the workgroup's ray pool (WgPool)
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
 	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
+	(void)wave;
 	// Workgroup ray pool, for the END of a launch.  A reservation from the global queue is a.chunk rays for one device atomic, and while
 	// the queue is long the wave that makes it keeps all of them (the pool stays empty: round 2's behaviour).  What a launch loses at
 	// its end is mostly the spread of the moments at which the waves next need rays (tools/wave_timeline.py: 110 us at 128 rays per
@@ -82,8 +134,8 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 	__syncthreads();
 	// a.endgame more chunks for every wave of the segment (64-bit product: the tuning overrides allow 1024 x 4096 x 1024 waves)
 	const uint32_t endgame_rays = (uint32_t)min((unsigned long long)a.endgame * a.chunk * max(1u, (gridDim.x * (kTraceThreads / 64)) / kNumSegments), 0xffffffffull);
-	const uint32_t total_lanes = gridDim.x * blockDim.x;
-	uint2 *my_spill = a.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+	const uint32_t total_lanes = gridDim.x * (uint32_t)kTraceThreads;
+	const SpillColumn<CAMERA> my_spill(a.spill);
 	const int home = blockIdx.x & (kNumSegments - 1);
 
 	// the clock the chip holds under THIS launch: shader cycles (s_memtime) against the constant 100 MHz counter (s_memrealtime) over the life
@@ -91,8 +143,8 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 	const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 	if(blockIdx.x == 0 && threadIdx.x == 0)
 	{
-		unsigned long long total = 0;
-		for(int s = 0; s < kNumSegments; ++s) total += a.count[s * kCursorStride];
+		unsigned long long total = CAMERA ? camera_args().rays : 0ull;
+		if(!CAMERA) for(int s = 0; s < kNumSegments; ++s) total += a.count[s * kCursorStride];
 		atomicAdd(&a.stats->rays, total);
 	}
 
@@ -105,7 +157,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 	F3 idir = f3(0, 0, 1);
 	bool nx = false, ny = false, nz = false;
 	uint32_t octinv = 7u;
-	float tmin = 0.0f, hit_t = 1e9f, hit_u = 0.0f, hit_v = 0.0f;
+	float tmin = CAMERA ? a.tmin : 0.0f, hit_t = 1e9f, hit_u = 0.0f, hit_v = 0.0f;
 	int32_t hit_idx = -1;
 	int sp = 0;
 	uint32_t ng_x = 0, ng_y = 0, tg_x = 0, tg_y = 0;
@@ -120,7 +172,7 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 	uint32_t st_maxdepth = 0;
 	bool any_overflow = false, exhausted = false;
 	uint32_t loc_next = 0, loc_end = 0; // wave-uniform: reserved but not yet started rays
-	const uint32_t seg_len_lanes = lane < kNumSegments ? a.count[lane * kCursorStride] : 0u;
+	const uint32_t seg_len_lanes = lane < kNumSegments ? (CAMERA ? camera_args().seg_paths : a.count[lane * kCursorStride]) : 0u;
 	uint32_t seg_done = 0;              // wave-uniform: segments found empty or exhausted
 	for(int sgm = 0; sgm < kNumSegments; ++sgm)
 		if(__builtin_amdgcn_readlane((int)seg_len_lanes, sgm) == 0) seg_done |= 1u << sgm;
@@ -193,29 +245,76 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 				if(cn == 0 && dry) exhausted = true;
 			}
 			const uint32_t begin = loc_next;
-			const uint32_t got = min(n_idle, loc_end - loc_next);
+			uint32_t got = min(n_idle, loc_end - loc_next);
+			if(CAMERA) got = min(got, 256u - (begin & 255u)); // (one refill stays inside one 256-position chunk = inside one 32x32 block of one frame: see below)
 			loc_next += got;
 			if(STATS && lane == 0) wp[6] += 1;
-			const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+			const uint32_t my_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u)); // idle lanes below this one
 			// results of the rays the idle lanes finished since the last refill (traversal.glsl:253-254: remap, write):
 			// written here, >= refill_min lanes at a time and with the remap load in flight next to the loads of the new
 			// rays, instead of by the 5 lanes that finish in an average trip with a dependent load-then-store of their own
 			int32_t flush_tri = -1;
 			if(flush && hit_idx != -1) flush_tri = a.tri_indices[hit_idx];
-			const bool take = !active && my_rank < got;
-			const uint32_t new_ray = begin + my_rank;
+			const bool take_slot = !active && my_rank < got;
+			const uint32_t slot_ray = begin + my_rank;
+			bool take_cam = false;       // CAMERA: the position holds a pixel of the image
+			uint32_t cam_ray = 0;        // CAMERA: `ray` = the path (frame ordinal, local pixel), not the queue position
 			float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 1, 0);
-			if(take)
+			if(CAMERA)
 			{
-				if(a.packed) { const F3 o3 = ld3((const float *)a.ray_o, new_ray); ro = make_float4(o3.x, o3.y, o3.z, a.tmin); }
-				else ro = a.ray_o[new_ray];
-				rd = a.ray_d[new_ray];
+				const TraceCameraArgs &R = camera_args();
+				if(flush) { camera_store_hit(R, ray, flush_tri, hit_u, hit_v); flush = false; }
+				// Queue position -> path.  The positions of a refill are consecutive and lie inside one 256-position chunk of one segment, and
+				// chunks map to runs of 256 paths (k_gen_primary's dealing: chunk c of segment s is chunk c * 8 + s of the pass, or the segments
+				// are contiguous runs), which lie inside one 1024-pixel block of one frame: frame, tmpLifetime group, sub-pixel bias and the
+				// block's place in the image are the same for the whole wave — scalar arithmetic, and the block table is read with a scalar load.
+				const uint32_t seg = begin >> R.seg_shift, rel = begin & ((1u << R.seg_shift) - 1u);
+				const uint32_t q0 = R.f.deal_chunks ? ((((rel >> 8) * kNumSegments + seg) << 8) | (rel & 255u)) : seg * R.seg_paths + rel;
+				const uint32_t npx = (uint32_t)R.f.n_local_px;
+				uint32_t ordinal = 0, l0 = q0;
+				if(R.f.n_frames != 1) { ordinal = q0 / npx; l0 = q0 - ordinal * npx; }
+				const bool in_pass = q0 < npx * (uint32_t)R.f.n_frames; // (the last chunks of the segments may lie beyond the pass)
+				const int blk = in_pass ? R.local_blocks[l0 >> 10] : 0;
+				const int blk_x = (blk % R.f.blocks_x) * kBlockDim, blk_y = (blk / R.f.blocks_x) * kBlockDim;
+				const int frame = R.f.frame_first + (int)ordinal * R.f.frame_stride;
+				const uint32_t group = frame == 0 ? 0u : (uint32_t)frame_group(R.f, frame);
+				float bx = 0.0f, by = 0.0f;
+				if(R.bias_mode)
+				{
+					const int sub_idx = ((R.f.spp + frame) / R.f.tmp_life) % (R.f.subpixel * R.f.subpixel);
+					const float unit = 1.0f / (float)R.f.subpixel;
+					bx = (float)(sub_idx / R.f.subpixel) * unit;
+					by = (float)(sub_idx % R.f.subpixel) * unit;
+				}
+				// per lane: the pixel inside the block (local_pixel_xy), the ray
+				const uint32_t in = (l0 & 1023u) + my_rank, wt = in >> 6, ln = in & 63u;
+				const int x = blk_x + (int)((wt & 3u) * 8u + (ln & 7u)), y = blk_y + (int)((wt >> 2) * 8u + (ln >> 3));
+				const bool take = take_slot && in_pass && x < R.f.width && y < R.f.height; // (pixels of a border block beyond the image have no ray)
+				const uint32_t new_ray = group * npx + l0 + my_rank; // `ray` of a camera pass: where the hit goes (camera_store_hit)
+				if(take)
+				{
+					const F3 d = camera_dir(R.f, x, y, bx, by);
+					ro = make_float4(R.f.origin[0], R.f.origin[1], R.f.origin[2], 0.0f);
+					rd = make_float4(d.x, d.y, d.z, 0.0f);
+				}
+				take_cam = take; cam_ray = new_ray;
 			}
-			if(flush)
+			const bool take = CAMERA ? take_cam : take_slot;
+			const uint32_t new_ray = CAMERA ? cam_ray : slot_ray;
+			if(!CAMERA)
 			{
-				if(a.packed) st3((float *)a.hit, ray, __int_as_float(flush_tri), hit_u, hit_v);
-				else a.hit[ray] = make_float4(__int_as_float(flush_tri), hit_u, hit_v, hit_t);
-				flush = false;
+				if(take)
+				{
+					if(a.packed) { const F3 o3 = ld3((const float *)a.ray_o, new_ray); ro = make_float4(o3.x, o3.y, o3.z, a.tmin); }
+					else ro = a.ray_o[new_ray];
+					rd = a.ray_d[new_ray];
+				}
+				if(flush)
+				{
+					if(a.packed) st3((float *)a.hit, ray, __int_as_float(flush_tri), hit_u, hit_v);
+					else a.hit[ray] = make_float4(__int_as_float(flush_tri), hit_u, hit_v, hit_t);
+					flush = false;
+				}
 			}
 			if(take)
 			{
@@ -231,10 +330,11 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 				nx = dir.x < 0; ny = dir.y < 0; nz = dir.z < 0;
 				octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
 				F3 origin = f3(ro.x, ro.y, ro.z);
-				tmin = ro.w;
+				if(!CAMERA) tmin = ro.w;
 				// make the ray loads complete inside this (rare) refill block: otherwise the compiler's s_waitcnt
 				// bookkeeping carries them into the traversal loop and drains the software-pipelined node fetch
-				asm volatile("" : "+v"(origin.x), "+v"(origin.y), "+v"(origin.z), "+v"(tmin));
+				if(CAMERA) asm volatile("" : "+v"(origin.x), "+v"(origin.y), "+v"(origin.z));
+				else asm volatile("" : "+v"(origin.x), "+v"(origin.y), "+v"(origin.z), "+v"(tmin));
 				od_x = v2(origin.x, dir.x); od_y = v2(origin.y, dir.y); od_z = v2(origin.z, dir.z);
 				hit_t = 1e9f; hit_u = 0.0f; hit_v = 0.0f; hit_idx = -1;
 				sp = 0;
@@ -259,7 +359,8 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 	if(flush) // rays finished after the queue ran dry
 	{
 		const int32_t tri_id = hit_idx != -1 ? a.tri_indices[hit_idx] : -1;
-		if(a.packed) st3((float *)a.hit, ray, __int_as_float(tri_id), hit_u, hit_v);
+		if(CAMERA) camera_store_hit(camera_args(), ray, tri_id, hit_u, hit_v);
+		else if(a.packed) st3((float *)a.hit, ray, __int_as_float(tri_id), hit_u, hit_v);
 		else a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
 	}
 	if(blockIdx.x == 0 && threadIdx.x == 0)
@@ -287,6 +388,17 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 			atomicMax(&a.stats->max_stack, st_maxdepth);
 		}
 	}
+}
+
+template <bool STATS, bool ANY = false>
+__global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_trace(TraceArgs a) // hot variant: <= 80 VGPRs, 6 waves per SIMD
+{
+	trace_loop<STATS, ANY, false>(a);
+}
+template <bool STATS>
+__global__ __launch_bounds__(kTraceThreads, (STATS ? 4 : 6)) void k_trace_camera(TraceCameraArgs K)
+{
+	trace_loop<STATS, false, true>(K.a);
 }
 
 }  // namespace adypt
