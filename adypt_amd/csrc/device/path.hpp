@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	const PathKernArgs &E = rare_args();
 	const PixelArgs &px = E.px;
 	if(lane == 0) { atomicAdd(&ctl->rays, wave_rays); if(wave_shaded) atomicAdd(&ctl->shaded, wave_shaded); if(wave_bad) atomicAdd(&px.stats->bad_materials, (unsigned long long)wave_bad); }
-	if(any_overflow) atomicAdd(&E.a.stats->overflows, 1ull);
+	if(any_overflow) report_overflow(E.a.stats);
 	__syncthreads();
 	if(threadIdx.x == 0)
 	{

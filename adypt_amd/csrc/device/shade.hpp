@@ -48,7 +48,11 @@ struct DeviceStats {                           // accumulated until adypt_reset_
 	unsigned long long clock_cycles, clock_ticks; // adypt_get_shader_clock: shader cycles / 100 MHz ticks of workgroup 0 over the traversal launches
 	unsigned long long path_rays, path_nodes, path_tris, path_hits, path_shaded; // k_path's share of rays / nodes / tris / hits / shaded
 	unsigned long long audit_errors;             // slot-claim audit (adypt_set_instrumentation flag 4): slots of an appended queue not written exactly once
+	uint32_t *host_overflow;                     // NOT a counter (set at adypt_create, kept by adypt_reset_stats): pinned host word a traversal kernel sets when a
+	                                             //   stack overflows, so that the host learns of it from the stream synchronisation alone (no copy per call)
 };
+// a traversal kernel's report of a stack overflow (traversal.glsl has none: its stack is a fixed local array)
+__device__ __forceinline__ void report_overflow(DeviceStats *st) { atomicAdd(&st->overflows, 1ull); *st->host_overflow = 1u; }
 
 struct RayStats { int32_t ref_idx; uint32_t nodes, tris, hash, max_depth, pad0, pad1, pad2; }; // 32 B, STATS variant
 
@@ -726,43 +730,35 @@ __global__ __launch_bounds__(kShadeThreads) void k_shadow_resolve(FrameArgs f, Q
 	finish_path(f, px, pi, L, ret);
 }
 
-// primaryray.glsl main (:46-94): colour the primary hit by viewer type.  The hit is in the cache image already (k_trace_camera wrote it
-// there, primaryray.glsl:93): one thread per local pixel, no queue.
-__global__ __launch_bounds__(kShadeThreads) void k_viewer(FrameArgs f, SceneArgs sc, PixelArgs px, int viewer_type)
+// primaryray.glsl main (:46-94): the colour of a primary hit by viewer type (k_trace_camera colours a pixel when its ray has finished)
+__device__ __forceinline__ F3 viewer_color(const FrameArgs &f, const SceneArgs &sc, DeviceStats *stats, int tri_idx, float u, float v, int viewer_type)
 {
-	ADYPT_VGPR_SLACK("v32");
-	const int L = (int)(blockIdx.x * kShadeThreads + threadIdx.x);
-	int x = 0, y = 0;
-	if(L >= f.n_local_px || !local_pixel_xy(f, sc.local_blocks, L, &x, &y)) return;
-	const float4 h = px.cache[L];
-	const int tri_idx = __float_as_int(h.x);
-	const float u = h.y, v = h.z;
 	F3 color = f3(0, 0, 0);
-	if(tri_idx != -1)
+	if(tri_idx == -1) return color;
+	const int matid = __float_as_int(sc.triangles[(size_t)tri_idx * kTriFloat4 + 4].z);
+	if(matid < 0 || matid >= f.n_mats) { atomicAdd(&stats->bad_materials, 1ull); return color; }
+	const float4 *mp = sc.materials + (size_t)matid * kMatFloat4;
+	const float w = 1.0f - u - v;
+	if(viewer_type == 0)
+	{
+		const float4 md = mp[0];
+		const int dtex = __float_as_int(md.x);
+		if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex)
+		{
+			const float4 mt = mp[4];
+			color = textured_diffuse(sc, tri_idx, make_int4(__float_as_int(mt.x), __float_as_int(mt.y), __float_as_int(mt.z), 0), u, v, w);
+		}
+		else color = f3(md.y, md.z, md.w);
+	}
+	else if(viewer_type == 1) { const float4 ms = mp[2]; color = f3(ms.y, ms.z, ms.w); }
+	else if(viewer_type == 2) { const float4 me = mp[1]; color = f3(me.y, me.z, me.w); }
+	else if(viewer_type == 4 || viewer_type == 5)
 	{
 		const TriCore tc = load_tri_core(sc, tri_idx);
 		const float *tri = tc.v;
-		const int matid = __float_as_int(tri[18]);
-		if(matid >= 0 && matid < f.n_mats)
-		{
-			const float4 *mp = sc.materials + (size_t)matid * kMatFloat4;
-			const float4 md = mp[0], me = mp[1], ms = mp[2], mt = mp[4];
-			const int dtex = __float_as_int(md.x);
-			const int4 tex_desc = make_int4(__float_as_int(mt.x), __float_as_int(mt.y), __float_as_int(mt.z), 0);
-			const float w = 1.0f - u - v;
-			if(viewer_type == 0)
-			{
-				if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) color = textured_diffuse(sc, tri_idx, tex_desc, u, v, w);
-				else color = f3(md.y, md.z, md.w);
-			}
-			else if(viewer_type == 1) color = f3(ms.y, ms.z, ms.w);
-			else if(viewer_type == 2) color = f3(me.y, me.z, me.w);
-			else if(viewer_type == 4) color = normalize3(bary3(tri + 9, tri + 12, tri + 15, u, v, w));
-			else if(viewer_type == 5) color = bary3(tri + 0, tri + 3, tri + 6, u, v, w);
-		}
-		else atomicAdd(&px.stats->bad_materials, 1ull);
+		color = viewer_type == 4 ? normalize3(bary3(tri + 9, tri + 12, tri + 15, u, v, w)) : bary3(tri + 0, tri + 3, tri + 6, u, v, w);
 	}
-	px.accum[L] = make_float4(color.x, color.y, color.z, 1.0f);
+	return color;
 }
 
 // screen.glsl main (:15-21): what the reference's full-screen quad shows for the result image — gamma 1/2.2 for the

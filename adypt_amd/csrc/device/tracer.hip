@@ -148,6 +148,7 @@ struct adypt_ctx {
 	size_t audit_words = 0;
 	FrameCounters *d_counters = nullptr; // [kMaxPipes]; pipe k uses d_counters + k
 	DeviceStats *d_stats = nullptr;
+	uint32_t *h_overflow = nullptr; // pinned: DeviceStats::host_overflow
 	uint2 *d_spill = nullptr;  // [kMaxPipes][stack_size - lds_depth][total lanes]
 	size_t spill_bytes = 0;
 	size_t lds_bytes = 0;      // dynamic LDS of a traversal launch (>= the stack's: padded when it has to cap the workgroups per CU)
@@ -485,7 +486,7 @@ inline QueueWindow pipe_window(const adypt_ctx *c, int k, int n_pipes)
 
 // Camera rays of a pass -> traversal -> cache images, one launch (k_trace_camera).  `f` names the frames of the pass (n_frames, frame_first,
 // frame_stride); the cursors of `ctr` must be clear.
-int launch_trace_camera(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, FrameCounters *ctr, const FrameArgs &f, const PixelArgs &px, int bias_mode, bool stats)
+int launch_trace_camera(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, FrameCounters *ctr, const FrameArgs &f, const PixelArgs &px, int bias_mode, bool stats, int viewer_type = -1)
 {
 	TraceCameraArgs K;
 	memset(&K, 0, sizeof(K));
@@ -503,8 +504,16 @@ int launch_trace_camera(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, 
 	a.stack_size = c->params.stack_size; a.lds_depth = c->lds_depth;
 	K.f = f; K.local_blocks = (const int32_t *)c->d_local_blocks; K.px = px; K.bias_mode = bias_mode;
 	hipEvent_t *stop = begin_timing(c, 0, pipe.stream);
-	if(stats) hipLaunchKernelGGL(k_trace_camera<true>, dim3(c->trace_blocks), dim3(kTraceThreads), c->lds_bytes, pipe.stream, K);
-	else hipLaunchKernelGGL(k_trace_camera<false>, dim3(c->trace_blocks), dim3(kTraceThreads), c->lds_bytes, pipe.stream, K);
+	const bool viewer = viewer_type >= 0; // a primary-only call: the pixel is coloured when its ray has finished (no viewer launch)
+	if(viewer) { fill_scene(c, &K.sc); K.viewer_type = viewer_type; }
+	const dim3 grid(c->trace_blocks), block(kTraceThreads);
+	if(viewer)
+	{
+		if(stats) hipLaunchKernelGGL((k_trace_camera<true, true>), grid, block, c->lds_bytes, pipe.stream, K);
+		else hipLaunchKernelGGL((k_trace_camera<false, true>), grid, block, c->lds_bytes, pipe.stream, K);
+	}
+	else if(stats) hipLaunchKernelGGL((k_trace_camera<true, false>), grid, block, c->lds_bytes, pipe.stream, K);
+	else hipLaunchKernelGGL((k_trace_camera<false, false>), grid, block, c->lds_bytes, pipe.stream, K);
 	end_timing(stop, pipe.stream);
 	HIP_TRY(c, hipGetLastError());
 	return ADYPT_OK;
@@ -524,9 +533,8 @@ QueueArgs queue_args(adypt_ctx *c, const QueueWindow &win, int in, const uint32_
 
 int check_async_errors(adypt_ctx *c)
 {
-	DeviceStats st;
-	HIP_TRY(c, hipMemcpy(&st, c->d_stats, sizeof(st), hipMemcpyDeviceToHost));
-	if(st.overflows) return fail(c, ADYPT_E_STACK_OVERFLOW, "traversal stack overflow: increase pathTracer.stackSize (currently " + std::to_string(c->params.stack_size) + ")");
+	// (after a synchronisation of the streams the kernels ran on: the word is in pinned host memory, the kernels write it themselves)
+	if(*(volatile uint32_t *)c->h_overflow) return fail(c, ADYPT_E_STACK_OVERFLOW, "traversal stack overflow: increase pathTracer.stackSize (currently " + std::to_string(c->params.stack_size) + ")");
 	return ADYPT_OK;
 }
 
@@ -913,6 +921,9 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	HIP_CREATE(hipMalloc((void **)&c->d_stats, sizeof(DeviceStats)));
 	HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(FrameCounters) * kMaxPipes));
 	HIP_CREATE(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
+	HIP_CREATE(hipHostMalloc((void **)&c->h_overflow, sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+	*c->h_overflow = 0u;
+	HIP_CREATE(hipMemcpy(&c->d_stats->host_overflow, &c->h_overflow, sizeof(uint32_t *), hipMemcpyHostToDevice));
 
 	// defaults of InstanceConfig::PT (src/InstanceConfig.hpp:21-27), seed 0
 	c->pending.stack_size = 12; c->pending.max_bounce = 5; c->pending.subpixel = 8; c->pending.tmp_lifetime = 16;
@@ -950,6 +961,7 @@ void adypt_destroy(adypt_ctx *c)
 		if(c->pipes[k].done) (void)hipEventDestroy(c->pipes[k].done);
 		if(k > 0 && c->pipes[k].stream) (void)hipStreamDestroy(c->pipes[k].stream);
 	}
+	if(c->h_overflow) (void)hipHostFree(c->h_overflow);
 	if(c->fork_ev) (void)hipEventDestroy(c->fork_ev);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -1091,14 +1103,9 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	const QueueWindow win = full_window(c);
 	FrameCounters *ctr = pipe.counters;
 	clear_counters(c, ctr, 1, c->stream);
-	// camera rays -> traversal -> cache image in one launch, then the viewer's colour per pixel (primaryray.glsl:46-94)
-	r = launch_trace_camera(c, pipe, win, ctr, f, px, 0, (c->instrumentation & 2) != 0);
+	// camera rays -> traversal -> cache image and the viewer's colour of every pixel (primaryray.glsl:46-94), one launch
+	r = launch_trace_camera(c, pipe, win, ctr, f, px, 0, (c->instrumentation & 2) != 0, viewer_type);
 	if(r != ADYPT_OK) return r;
-	{
-		hipEvent_t *stop = begin_timing(c, 1, c->stream);
-		hipLaunchKernelGGL(k_viewer, dim3((unsigned)(c->n_local_px / kShadeThreads)), dim3(kShadeThreads), 0, c->stream, f, sc, px, viewer_type);
-		end_timing(stop, c->stream);
-	}
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	harvest_events(c);
@@ -1505,8 +1512,9 @@ int adypt_reset_stats(adypt_ctx *c)
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	harvest_events(c);
 	// on the context's own stream: a legacy-stream hipMemset is not ordered against a non-blocking stream
-	HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(DeviceStats), c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, offsetof(DeviceStats, host_overflow), c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	*c->h_overflow = 0u;
 	c->trace_ms = c->shade_ms = c->path_ms = 0; c->trace_launches = c->path_launches = 0;
 	return ADYPT_OK;
 }

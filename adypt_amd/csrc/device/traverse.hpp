@@ -95,7 +95,9 @@ struct TraceCameraArgs {            // the ONE parameter of k_trace_camera (offs
 	unsigned long long rays;        //   camera rays of the pass (in-image pixels of the owned blocks x frames)
 	FrameArgs f;                    //   n_frames / frame_first / frame_stride: the frames of the pass
 	const int32_t *local_blocks;
-	PixelArgs px;                   //   cache, cache_next: where the hits go
+	PixelArgs px;                   //   cache, cache_next: where the hits go; accum: VIEWER's colours
+	SceneArgs sc;                   //   VIEWER only
+	int32_t viewer_type;            //   VIEWER only (primaryray.glsl's uType)
 	int32_t bias_mode;              //   0: Camera() of primaryray.glsl; 1: Camera(SubPixel()) of pathtracer.glsl
 };
 // read where they are used (the refill block), not held in SGPRs across the persistent loop (see k_path's rare_args())
@@ -113,8 +115,14 @@ __device__ __forceinline__ void camera_store_hit(const TraceCameraArgs &R, uint3
 	float4 *dst = where < n ? R.px.cache + where : R.px.cache_next + (where - n);
 	*dst = make_float4(__int_as_float(tri), u, v, 0.0f);
 }
+// VIEWER (a primary-only call, one frame): the pixel's colour as well (primaryray.glsl:46-94) — `where` is the local pixel
+__device__ __forceinline__ void camera_store_view(const TraceCameraArgs &R, uint32_t where, int32_t tri, float u, float v)
+{
+	const F3 c = viewer_color(R.f, R.sc, R.px.stats, tri, u, v, R.viewer_type);
+	R.px.accum[where] = make_float4(c.x, c.y, c.z, 1.0f);
+}
 
-template <bool STATS, bool ANY, bool CAMERA>
+template <bool STATS, bool ANY, bool CAMERA, bool VIEWER = false>
 __device__ __forceinline__ void trace_loop(const TraceArgs a)
 {
 	constexpr bool kUniformTmin = CAMERA; // ray batches handed in by the caller carry a tmin per ray; camera rays the pass's
@@ -263,7 +271,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 			if(CAMERA)
 			{
 				const TraceCameraArgs &R = camera_args();
-				if(flush) { camera_store_hit(R, ray, flush_tri, hit_u, hit_v); flush = false; }
+				if(flush) { camera_store_hit(R, ray, flush_tri, hit_u, hit_v); if(VIEWER) camera_store_view(R, ray, flush_tri, hit_u, hit_v); flush = false; }
 				// Queue position -> path.  The positions of a refill are consecutive and lie inside one 256-position chunk of one segment, and
 				// chunks map to runs of 256 paths (k_gen_primary's dealing: chunk c of segment s is chunk c * 8 + s of the pass, or the segments
 				// are contiguous runs), which lie inside one 1024-pixel block of one frame: frame, tmpLifetime group, sub-pixel bias and the
@@ -359,7 +367,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 	if(flush) // rays finished after the queue ran dry
 	{
 		const int32_t tri_id = hit_idx != -1 ? a.tri_indices[hit_idx] : -1;
-		if(CAMERA) camera_store_hit(camera_args(), ray, tri_id, hit_u, hit_v);
+		if(CAMERA) { const TraceCameraArgs &R = camera_args(); camera_store_hit(R, ray, tri_id, hit_u, hit_v); if(VIEWER) camera_store_view(R, ray, tri_id, hit_u, hit_v); }
 		else if(a.packed) st3((float *)a.hit, ray, __int_as_float(tri_id), hit_u, hit_v);
 		else a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
 	}
@@ -368,7 +376,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 		atomicAdd(&a.stats->clock_cycles, __builtin_readcyclecounter() - clk_c0);
 		atomicAdd(&a.stats->clock_ticks, __builtin_amdgcn_s_memrealtime() - clk_r0);
 	}
-	if(any_overflow) atomicAdd(&a.stats->overflows, 1ull);
+	if(any_overflow) report_overflow(a.stats);
 	if(STATS)
 	{
 		for(int off = 32; off > 0; off >>= 1)
@@ -395,10 +403,10 @@ __global__ __launch_bounds__(kTraceThreads, ((STATS || ANY) ? 4 : 6)) void k_tra
 {
 	trace_loop<STATS, ANY, false>(a);
 }
-template <bool STATS>
+template <bool STATS, bool VIEWER>
 __global__ __launch_bounds__(kTraceThreads, (STATS ? 4 : 6)) void k_trace_camera(TraceCameraArgs K)
 {
-	trace_loop<STATS, false, true>(K.a);
+	trace_loop<STATS, false, true, VIEWER>(K.a);
 }
 
 }  // namespace adypt

@@ -40,8 +40,8 @@ edit("shade.hpp", [("const TriCore tc = load_tri_core(sc, tri_idx);\n\tconst flo
                     "const TriCore tc = load_tri_core(sc, ADYPT_MEASURE_SHADE_GATHER_INDEX(tri_idx));\n\tconst float *tri = tc.v;\n\tconst int matid = __float_as_int(tri[18]);\n\t// the hit's geometry")])
 edit("traverse.hpp", [
     ("constexpr int kNodeUint4 = 5;", "#ifndef ADYPT_MEASURE_FP16_NODES\nconstexpr int kNodeUint4 = 5;\n#endif //"),
-    ("\tconst unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();\n\tif(blockIdx.x == 0 && threadIdx.x == 0)\n\t{\n\t\tunsigned long long total = 0;",
-     "\tADYPT_MEASURE_WAVE_BEGIN();\n\tconst unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();\n\tif(blockIdx.x == 0 && threadIdx.x == 0)\n\t{\n\t\tunsigned long long total = 0;"),
+    ("\tconst unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();\n\tif(blockIdx.x == 0 && threadIdx.x == 0)\n\t{\n\t\tunsigned long long total = CAMERA",
+     "\tADYPT_MEASURE_WAVE_BEGIN();\n\tconst unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();\n\tif(blockIdx.x == 0 && threadIdx.x == 0)\n\t{\n\t\tunsigned long long total = CAMERA"),
     ("\t\t\t\tif(cn == 0 && dry) exhausted = true;\n", "\t\t\t\tif(cn == 0 && dry) { exhausted = true; ADYPT_MEASURE_WAVE_QUEUE_DRY(); }\n\t\t\t\telse if(cn) { ADYPT_MEASURE_WAVE_FIRST_RAYS(); }\n"),
     ("\tif(blockIdx.x == 0 && threadIdx.x == 0)\n\t{\n\t\tatomicAdd(&a.stats->clock_cycles,", "\tADYPT_MEASURE_WAVE_END(a.stats);\n\tif(blockIdx.x == 0 && threadIdx.x == 0)\n\t{\n\t\tatomicAdd(&a.stats->clock_cycles,"),
 ])
