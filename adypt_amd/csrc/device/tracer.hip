@@ -156,10 +156,12 @@ struct adypt_ctx {
 	// launch geometry of the persistent traversal kernel
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0, occupancy_api = 0;
 	uint32_t refill_min = kRefillMin, chunk = kChunk, bite = kBite, endgame = kEndgame;
-	// Camera rays come in queue order = 8x8 pixel tiles, so a wave's rays are coherent and finish together: refilling only when half the wave is
-	// idle keeps whole half-tiles together.  Measured (round 4, primary rays only, 1080p): threshold 16 / 24 / 28 / 32 / 36 -> 0.410 / 0.416 /
-	// 0.406 / 0.382 / 0.516 ms per call.  Secondary rays are incoherent and keep the lower threshold.
-	uint32_t refill_min_primary = 32;
+	// Camera rays come in queue order = 8x8 pixel tiles, so a wave's rays are coherent and finish together: a wave takes a WHOLE tile when all its
+	// lanes are idle (refill threshold 64, bites of 64 from the workgroup's reservation) and its lanes then walk the same nodes.  Measured (round 4,
+	// k_trace_camera, primary rays only, 1080p; profiles/r4_ablations_k_path.txt item 17): threshold / bite 8/8, 16/16, 32/32, 48/48, 64/64 ->
+	// 0.422 / 0.361 / 0.326 / 0.381 / 0.291 ms per launch; thresholds off the bite (28, 36 with bite 32) cost 8-38 %.  Secondary rays are
+	// incoherent and keep the low threshold.
+	uint32_t refill_min_primary = 64, bite_primary = 64;
 	int first_fused = 1;           // ADYPT_FIRST_FUSED=0: camera rays and bounce 0 of a batch as k_gen_primary + k_shade (rounds 1-2)
 	int fused_bounces = 1;         // bounces 1 .. maxBounce-1 of a batch in ONE launch (k_path, path.hpp); ADYPT_FUSED_BOUNCES=0: k_trace + k_shade per bounce
 	int path_blocks = 0, path_lds_depth = 0; // launch geometry of k_path
@@ -421,7 +423,7 @@ int launch_trace(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int par
 	a.spill = pipe.spill;
 	a.stats = c->d_stats;
 	a.seg_cap = win.seg_cap;
-	a.refill_min = camera_rays ? c->refill_min_primary : c->refill_min; a.chunk = c->chunk; a.bite = c->bite; a.endgame = c->endgame;
+	a.refill_min = camera_rays ? c->refill_min_primary : c->refill_min; a.chunk = c->chunk; a.bite = camera_rays ? c->bite_primary : c->bite; a.endgame = c->endgame;
 	a.stack_size = stack_size; a.lds_depth = c->lds_depth;
 	const size_t lds = c->lds_bytes;
 	hipEvent_t *stop = begin_timing(c, 0, pipe.stream);
@@ -500,7 +502,7 @@ int launch_trace_camera(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, 
 	while((1u << K.seg_shift) < K.seg_paths) ++K.seg_shift;
 	a.seg_cap = 1u << K.seg_shift; // (positions are numbers: nothing is stored at them)
 	K.rays = (unsigned long long)c->n_image_px * (unsigned long long)f.n_frames;
-	a.refill_min = c->refill_min_primary; a.chunk = c->chunk; a.bite = c->bite; a.endgame = c->endgame;
+	a.refill_min = c->refill_min_primary; a.chunk = c->chunk; a.bite = c->bite_primary; a.endgame = c->endgame;
 	a.stack_size = c->params.stack_size; a.lds_depth = c->lds_depth;
 	K.f = f; K.local_blocks = (const int32_t *)c->d_local_blocks; K.px = px; K.bias_mode = bias_mode;
 	hipEvent_t *stop = begin_timing(c, 0, pipe.stream);
@@ -805,7 +807,8 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	if(const char *ov = getenv("ADYPT_SHADE_MIN")) c->shade_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_ENDGAME")) c->endgame = (uint32_t)std::max(0, std::min(1024, atoi(ov)));
-	if(const char *ov = getenv("ADYPT_BITE")) c->bite = (uint32_t)std::max(1, std::min(4096, atoi(ov)));
+	if(const char *ov = getenv("ADYPT_BITE")) c->bite = c->bite_primary = (uint32_t)std::max(1, std::min(4096, atoi(ov)));
+	if(const char *ov = getenv("ADYPT_BITE_PRIMARY")) c->bite_primary = (uint32_t)std::max(1, std::min(4096, atoi(ov)));
 
 	c->n_nodes = d->n_nodes; c->n_refs = d->n_refs; c->n_tris = d->n_tris; c->n_mats = d->n_mats; c->n_tex = d->n_textures;
 	c->width = d->width; c->height = d->height; c->rank = d->tile_rank; c->nranks = d->tile_nranks;
@@ -1294,7 +1297,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 				FrameCounters *ctr = pipe.counters;
 				if(!(b == 0 && use_cache))
 				{
-					int r = launch_trace(c, pipe, sub[k].win, in, ctr->count[b], ctr->cursor[b], c->params.stack_size, stats, nullptr, false, false, true);
+					int r = launch_trace(c, pipe, sub[k].win, in, ctr->count[b], ctr->cursor[b], c->params.stack_size, stats, nullptr, false, false, true, b == 0); // (b == 0: camera rays from the queue, tile by tile)
 					if(r != ADYPT_OK) return abandon(r);
 				}
 				QueueArgs q = queue_args(c, sub[k].win, in, ctr->count[b], ctr->count[b + 1], sub[k].f.n_frames);
