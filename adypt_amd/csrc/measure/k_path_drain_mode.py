@@ -1,7 +1,8 @@
 """Measurement variant of k_path (NOT product code): "drain mode" for the end of a launch (profiles/r4_ablations_k_path.txt items 15, 16, 20).
 Once the global queue is dry (PathCtl::busy bit 1) and the workgroup holds at most ADYPT_DRAIN_LIVE paths, waves 2-3 take no more rays; when
 their own have ended they shade what waits in the to-shade ring WITHOUT parking (nothing to park), beside each other and beside a parking wave,
-at a threshold of max(1, live >> ADYPT_DRAIN_SHIFT) paths per round; waves 0-1 trace.
+at a threshold of max(1, live >> ADYPT_DRAIN_SHIFT) paths per round; waves 0-1 trace.  -DADYPT_DRAIN_BY_SLOT: the quiet waves are chosen by their
+slot on the SIMD instead (see below).
     tools/build_variant.sh drain --transform adypt_amd/csrc/measure/k_path_drain_mode.py -DADYPT_DRAIN_LIVE=128 -DADYPT_DRAIN_SHIFT=3"""
 import sys
 p = sys.argv[1] + "/path.hpp"
@@ -22,10 +23,20 @@ rep("#ifndef ADYPT_PATH_WAVES", """#ifndef ADYPT_DRAIN_LIVE
 #endif
 #ifndef ADYPT_PATH_WAVES""")
 rep("struct PathArgs {", "constexpr uint32_t kBusyShading = 1u, kBusyDry = 2u; // PathCtl::busy\nstruct PathArgs {")
+# which waves go quiet: waves 2-3 of every workgroup (default), or — -DADYPT_DRAIN_BY_SLOT — every wave but the workgroup's first whose slot on its
+# SIMD (HW_REG_HW_ID.WAVE_ID) is odd: if wave w of a workgroup always sits on SIMD w, quieting waves 2-3 empties two SIMDs and leaves the other two as
+# crowded as before
+rep("\tconst float tmin = a.tmin;\n", """\tconst float tmin = a.tmin;
+#ifdef ADYPT_DRAIN_BY_SLOT
+\tconst bool quiet_wave = uni(threadIdx.x) >= 64u && (__builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | ((4 - 1) << 11)) & 1u) != 0u;
+#else
+\tconst bool quiet_wave = uni(threadIdx.x) >= 128u;
+#endif
+""")
 rep("ctl->n_trace = have > (uint32_t)kTraceThreads ? have - (uint32_t)kTraceThreads : 0u; }",
     "ctl->n_trace = have > (uint32_t)kTraceThreads ? have - (uint32_t)kTraceThreads : 0u; if(have < (uint32_t)kPathSlots) ctl->busy = kBusyDry; }")
 rep("""			if(n_flush != 0u || pk_trace != 0u || (pk_shade + n_flush >= pk_thr && !pk_busy))""",
-    """			const bool drain = (pk_busy & kBusyDry) != 0u && pk_live <= (uint32_t)ADYPT_DRAIN_LIVE && uni(threadIdx.x) >= 128u;
+    """			const bool drain = (pk_busy & kBusyDry) != 0u && pk_live <= (uint32_t)ADYPT_DRAIN_LIVE && quiet_wave;
 			const uint32_t pk_free_thr = max(1u, pk_live >> ADYPT_DRAIN_SHIFT);
 			if(n_flush != 0u || (pk_trace != 0u && !drain) || (pk_shade + n_flush >= pk_thr && !(pk_busy & kBusyShading)) || (drain && n_idle == 64u && pk_shade >= pk_free_thr))""")
 rep("""				const bool do_shade = n_s >= thr && n_s != 0u && uni(ctl->busy) == 0u; // one shading wave per workgroup at a time: one parking area""",
