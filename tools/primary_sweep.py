@@ -1,3 +1,5 @@
+"""Developer tool (GPU box): ms per adypt_trace_primary call (BASELINE config 2, 1080p bench scene, 300 calls, timing events on) and per k_trace_camera
+launch for a list of environment settings, each in its own process, two rounds.   python tools/primary_sweep.py "base" "ADYPT_BITE_PRIMARY=32 ADYPT_REFILL_MIN_PRIMARY=32" ..."""
 import json, os, subprocess, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 code = r'''

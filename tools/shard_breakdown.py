@@ -1,3 +1,6 @@
+"""Developer tool (GPU box): every rank of an N-way pixel-tile split rendered on ONE GPU, one after the other (N = 1, 8, 4): wall time of a 20-frame batch,
+rays, and the batch's kernel time by part (k_path / camera rays + k_shade_first / the rest) — is the work balanced over the ranks, and where does a
+shard's time go?   python tools/shard_breakdown.py"""
 import json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from adypt_amd import api, scenes
