@@ -16,7 +16,7 @@ flags = [f for f in flags if f not in ("-fPIC",)]
 with tempfile.NamedTemporaryFile(suffix=".s") as t:
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DADYPT_BUILD", "--cuda-device-only", "-S", os.path.join(CSRC, "device/tracer.hip"), "-o", t.name], stderr=subprocess.DEVNULL)
     text = open(t.name).read()
-name = {"k_trace": "_ZN5adypt7k_traceILb0ELb0EEEvNS_9TraceArgsE", "k_path": "_ZN5adypt6k_pathILb0EEEvNS_8PathArgsENS_9FrameArgsENS_9SceneArgsENS_9PixelArgsEi"}[which]
+name = {"k_trace": "_ZN5adypt7k_traceILb0ELb0EEEvNS_9TraceArgsE", "k_path": "_ZN5adypt6k_pathILb0EEEvNS_12PathKernArgsE"}[which]
 body = text[text.index("\n" + name + ":"):text.index(".amdhsa_kernel " + name)].splitlines()
 
 FULL = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_add_u32", "v_sub_u32",
