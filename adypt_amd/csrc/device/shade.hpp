@@ -1,10 +1,12 @@
-// gfx950 kernels of the wavefront path tracer (everything except the traversal kernel, which lives in trace.hpp).
+// gfx950 kernels of the wavefront path tracer (everything except the traversal kernels, which live in traverse.hpp and path.hpp).
 //
-//   k_gen_primary       camera rays + path-state init                   (shaders/pathtracer.glsl:206-224, primaryray.glsl:39-49)
+//   k_gen_primary       camera rays + path-state init, into the queue   (shaders/pathtracer.glsl:206-224, primaryray.glsl:39-49; the launch-per-bounce
+//                                                                        pipeline: k_trace_camera computes camera rays itself)
+//   k_shade_first       camera ray + bounce 0 of every frame of a batch from the cached primary hit
 //   k_shade             one bounce of Render(): FetchInfo, scatter, compaction, accumulate on termination
 //                                                                       (shaders/pathtracer.glsl:73-204,224-226)
-//   k_viewer            primary-ray viewer colouring                    (shaders/primaryray.glsl:50-94)
-//   k_untile            compact block-major radiance -> W x H RGB
+//   viewer_color        primary-ray viewer colouring, called by k_trace_camera when a ray has finished (shaders/primaryray.glsl:50-94)
+//   k_resolve, k_display, k_untile   running mean in frame order; the window's display transform; compact block-major radiance -> W x H RGB
 //
 // Ray queue = 8 XCD-affine segments.  Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MB
 // L2), so workgroup b of every kernel works on segment b & 7: rays stay with "their" XCD from bounce to bounce, the

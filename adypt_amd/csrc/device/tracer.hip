@@ -147,6 +147,7 @@ struct adypt_ctx {
 	bool audit_selftest = false;      // ADYPT_AUDIT_SELFTEST=1: a double claim is planted before every check (tests that the detector detects)
 	size_t audit_words = 0;
 	FrameCounters *d_counters = nullptr; // [kMaxPipes]; pipe k uses d_counters + k
+	uint32_t *d_camera_cursors = nullptr; // k_trace_camera's own fetch cursors [kNumSegments][kCursorStride] + its counts of workgroups that have left [kNumSegments + 1][kCursorStride]: zero between launches (the kernel leaves them so)
 	DeviceStats *d_stats = nullptr;
 	uint32_t *h_overflow = nullptr; // pinned: DeviceStats::host_overflow
 	uint2 *d_spill = nullptr;  // [kMaxPipes][stack_size - lds_depth][total lanes]
@@ -486,16 +487,16 @@ inline QueueWindow pipe_window(const adypt_ctx *c, int k, int n_pipes)
 	return QueueWindow{(size_t)k * (size_t)cap * kNumSegments, cap};
 }
 
-// Camera rays of a pass -> traversal -> cache images, one launch (k_trace_camera).  `f` names the frames of the pass (n_frames, frame_first,
-// frame_stride); the cursors of `ctr` must be clear.
-int launch_trace_camera(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, FrameCounters *ctr, const FrameArgs &f, const PixelArgs &px, int bias_mode, bool stats, int viewer_type = -1)
+// Camera rays of a pass -> traversal -> cache images, one launch (k_trace_camera) and nothing in front of it.  `f` names the frames of the pass
+// (n_frames, frame_first, frame_stride).  On the context's stream only: the launches share one set of fetch cursors.
+int launch_trace_camera(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, const FrameArgs &f, const PixelArgs &px, int bias_mode, bool stats, int viewer_type = -1)
 {
 	TraceCameraArgs K;
 	memset(&K, 0, sizeof(K));
 	TraceArgs &a = K.a;
 	a.nodes = (const uint4 *)c->d_nodes; a.woop = (const float4 *)c->d_woop; a.tri_indices = (const int32_t *)c->d_tri_indices;
 	a.packed = 1u; a.tmin = c->params.ray_tmin;
-	a.cursor = ctr->cursor[0];
+	a.cursor = c->d_camera_cursors; K.left = c->d_camera_cursors + kNumSegments * kCursorStride;
 	a.spill = pipe.spill; a.stats = c->d_stats;
 	K.seg_paths = pass_seg_paths(c, win, f.n_frames);
 	K.seg_shift = 8;
@@ -923,6 +924,8 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	for(int k = 0; k < kMaxPipes; ++k) c->pipes[k].counters = c->d_counters + k;
 	HIP_CREATE(hipMalloc((void **)&c->d_stats, sizeof(DeviceStats)));
 	HIP_CREATE(hipMemset(c->d_counters, 0, sizeof(FrameCounters) * kMaxPipes));
+	HIP_CREATE(hipMalloc((void **)&c->d_camera_cursors, sizeof(uint32_t) * (2 * kNumSegments + 1) * kCursorStride));
+	HIP_CREATE(hipMemset(c->d_camera_cursors, 0, sizeof(uint32_t) * (2 * kNumSegments + 1) * kCursorStride));
 	HIP_CREATE(hipMemset(c->d_stats, 0, sizeof(DeviceStats)));
 	HIP_CREATE(hipHostMalloc((void **)&c->h_overflow, sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
 	*c->h_overflow = 0u;
@@ -952,7 +955,7 @@ void adypt_destroy(adypt_ctx *c)
 	for(EventPair &p : c->free_events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	void *bufs[] = {c->sh_o, c->sh_d, c->sh_col, c->sh_hit, c->d_all_blocks, c->d_nodes, c->d_woop, c->d_tri_indices, c->d_triangles, c->d_materials, c->d_tri_class, c->d_texels, c->d_ref_triangles, c->d_local_blocks,
 					c->d_accum, c->d_cache, c->d_cache_next, c->d_shift, c->q_o[0], c->q_o[1], c->q_d[0], c->q_d[1], c->q_col[0], c->q_col[1],
-					c->d_hit, c->d_ray_stats, c->d_audit_seen, c->d_counters, c->d_stats, c->d_spill, c->d_done, c->d_sobol, c->d_display};
+					c->d_hit, c->d_ray_stats, c->d_audit_seen, c->d_counters, c->d_camera_cursors, c->d_stats, c->d_spill, c->d_done, c->d_sobol, c->d_display};
 	for(void *b : bufs) if(b) (void)hipFree(b);
 	for(int i = 0; i < adypt_ctx::kSobolSlots; ++i)
 	{
@@ -1104,10 +1107,8 @@ int adypt_trace_primary(adypt_ctx *c, int viewer_type)
 	fill_frame(c, &f); fill_scene(c, &sc); fill_pixels(c, &px);
 	const Pipe &pipe = c->pipes[0];
 	const QueueWindow win = full_window(c);
-	FrameCounters *ctr = pipe.counters;
-	clear_counters(c, ctr, 1, c->stream);
-	// camera rays -> traversal -> cache image and the viewer's colour of every pixel (primaryray.glsl:46-94), one launch
-	r = launch_trace_camera(c, pipe, win, ctr, f, px, 0, (c->instrumentation & 2) != 0, viewer_type);
+	// camera rays -> traversal -> cache image and the viewer's colour of every pixel (primaryray.glsl:46-94): one launch is the whole call
+	r = launch_trace_camera(c, pipe, win, f, px, 0, (c->instrumentation & 2) != 0, viewer_type);
 	if(r != ADYPT_OK) return r;
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1217,10 +1218,8 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			// (on the context's stream, in the whole queue: every sub-batch below starts from these cache images)
 			const Pipe &pipe = c->pipes[0];
 			const QueueWindow win = full_window(c);
-			FrameCounters *ctr = pipe.counters;
-			clear_counters(c, ctr, 1, c->stream);
 			f.n_frames = n_retrace; f.frame_first = first_retrace; f.frame_stride = life;
-			int r = launch_trace_camera(c, pipe, win, ctr, f, px, 1, stats);
+			int r = launch_trace_camera(c, pipe, win, f, px, 1, stats);
 			if(r != ADYPT_OK) return r;
 			f.frame_stride = 1;
 		}

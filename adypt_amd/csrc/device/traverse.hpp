@@ -28,7 +28,7 @@ constexpr int kRefillMin = 16; // default: refill when at least this many lanes 
 constexpr int kChunk = 128;    // default: rays a workgroup reserves per queue atomic
 constexpr int kBite = 32;      // default: rays a wave takes from its workgroup's reservation at a time (end of a launch)
 constexpr int kEndgame = 4;    // default: the end of a launch = fewer than this many more chunks per wave left in the segment
-struct WgPool { unsigned long long range; uint32_t lock, dry; }; // range = (end << 32) | next: reserved, not yet handed to a wave
+struct WgPool { unsigned long long range; uint32_t lock, dry, left, pad; }; // range = (end << 32) | next: reserved, not yet handed to a wave; left: waves that have left the loop (k_trace_camera)
 constexpr int kNodeUint4 = 5;  // the 80-byte WideBVHNode, verbatim (src/BVH/WideBVH.hpp:13-26)
 
 // The lane's column of the HBM spill array (stack entries beyond the LDS depth): my_spill[depth x lanes of the launch].  AT_USE: the column's
@@ -93,6 +93,9 @@ struct TraceCameraArgs {            // the ONE parameter of k_trace_camera (offs
 	uint32_t seg_paths;             //   queue positions per segment (QueueArgs::seg_paths of the pass; a multiple of 256)
 	uint32_t seg_shift;             //   position = segment << seg_shift | place in the segment
 	unsigned long long rays;        //   camera rays of the pass (in-image pixels of the owned blocks x frames)
+	uint32_t *left;                 //   [kNumSegments + 1][kCursorStride] workgroups that have left the launch, per home segment, and segments complete.
+	                                //   a.cursor and these words belong to camera launches alone and are zero between them: the last workgroup to
+	                                //   leave a launch puts them back (no clearing launch in front of a primary-only call)
 	FrameArgs f;                    //   n_frames / frame_first / frame_stride: the frames of the pass
 	const int32_t *local_blocks;
 	PixelArgs px;                   //   cache, cache_next: where the hits go; accum: VIEWER's colours
@@ -138,7 +141,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 	// fewer rays in its segment than one more chunk for every wave, the chunk goes into the pool and the 4 waves take it a.bite rays
 	// at a time (LDS compare-and-swap): the rays a wave can be left holding shrink 4x at the same number of device atomics.
 	WgPool *pool = (WgPool *)(lds_stack + (size_t)(kTraceThreads / 64) * a.lds_depth * 64);
-	if(threadIdx.x == 0) { pool->range = 0ull; pool->lock = 0u; pool->dry = 0u; }
+	if(threadIdx.x == 0) { pool->range = 0ull; pool->lock = 0u; pool->dry = 0u; pool->left = 0u; }
 	__syncthreads();
 	// a.endgame more chunks for every wave of the segment (64-bit product: the tuning overrides allow 1024 x 4096 x 1024 waves)
 	const uint32_t endgame_rays = (uint32_t)min((unsigned long long)a.endgame * a.chunk * max(1u, (gridDim.x * (kTraceThreads / 64)) / kNumSegments), 0xffffffffull);
@@ -370,6 +373,22 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 		if(CAMERA) { const TraceCameraArgs &R = camera_args(); camera_store_hit(R, ray, tri_id, hit_u, hit_v); if(VIEWER) camera_store_view(R, ray, tri_id, hit_u, hit_v); }
 		else if(a.packed) st3((float *)a.hit, ray, __int_as_float(tri_id), hit_u, hit_v);
 		else a.hit[ray] = make_float4(__int_as_float(tri_id), hit_u, hit_v, hit_t);
+	}
+	if(CAMERA && lane == 0)
+	{
+		// Every fetch of this wave has returned (the loop used their results).  The last wave of the launch to get here zeroes the cursors — counted
+		// wave -> workgroup (LDS) -> home segment -> launch, so that no counter takes more than a few hundred atomics (all 6144 waves on one word
+		// held the end of the launch up by 35 us: a single address takes ~88 atomics per us on this chip)
+		if(__hip_atomic_fetch_add(&pool->left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)(kTraceThreads / 64) - 1u)
+		{
+			const TraceCameraArgs &R = camera_args();
+			const uint32_t in_segment = (gridDim.x + (uint32_t)(kNumSegments - 1 - home)) / (uint32_t)kNumSegments; // workgroups whose home this segment is
+			if(atomicAdd(&R.left[home * kCursorStride], 1u) == in_segment - 1u && atomicAdd(&R.left[kNumSegments * kCursorStride], 1u) == (uint32_t)min((uint32_t)kNumSegments, gridDim.x) - 1u)
+			{
+				for(int s = 0; s < kNumSegments; ++s) { R.a.cursor[s * kCursorStride] = 0u; R.left[s * kCursorStride] = 0u; }
+				R.left[kNumSegments * kCursorStride] = 0u;
+			}
+		}
 	}
 	if(blockIdx.x == 0 && threadIdx.x == 0)
 	{

@@ -291,7 +291,7 @@ def test_full_size_frame_bit_exact_and_deterministic(scene_cache, sobol_matrices
 def test_bench_path_batched_1080p_spanning_two_tmplifetime_groups(scene_cache, sobol_matrices):
     """Exactly what bench.py times (its scene, its .config parameters, the default 32 frames in flight): a warm-up call of
     5 frames, then ONE call of 20 frames = frames 5..24 of the sequence.  That batch spans two tmpLifetime groups (frame 16
-    re-traces its primaries): primary-only pass -> k_store_cache into the second cache slice -> every frame starts from the
+    re-traces its primaries): primary-only pass (k_trace_camera) into the second cache slice -> every frame starts from the
     cache of its group -> k_resolve in frame order -> image 1 = the last group's hits (tracer.hip adypt_trace_spp_async).
     Against the oracle's frame-by-frame loop (pathtracer.glsl:113-127, OglPathTracer.cpp:34-61), every pixel, every bit."""
     pt_cfg = {"maxBounce": 8, "subpixel": 8, "tmpLifetime": 16, "clamp": 4.0, "sun": [12.0, 11.0, 10.0], "stackSize": 24}  # = bench.py
