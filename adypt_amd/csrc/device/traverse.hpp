@@ -133,7 +133,6 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
 	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
-	(void)wave;
 	// Workgroup ray pool, for the END of a launch.  A reservation from the global queue is a.chunk rays for one device atomic, and while
 	// the queue is long the wave that makes it keeps all of them (the pool stays empty: round 2's behaviour).  What a launch loses at
 	// its end is mostly the spread of the moments at which the waves next need rays (tools/wave_timeline.py: 110 us at 128 rays per
@@ -269,7 +268,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 			const bool take_slot = !active && my_rank < got;
 			const uint32_t slot_ray = begin + my_rank;
 			bool take_cam = false;       // CAMERA: the position holds a pixel of the image
-			uint32_t cam_ray = 0;        // CAMERA: `ray` = the path (frame ordinal, local pixel), not the queue position
+			uint32_t cam_ray = 0;        // CAMERA: `ray` = where the hit goes (tmpLifetime group x local pixels + local pixel), not the queue position
 			float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 1, 0);
 			if(CAMERA)
 			{
