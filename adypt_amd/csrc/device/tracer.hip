@@ -165,6 +165,7 @@ struct adypt_ctx {
 	uint32_t refill_min_primary = 64, bite_primary = 64;
 	int first_fused = 1;           // ADYPT_FIRST_FUSED=0: camera rays and bounce 0 of a batch as k_gen_primary + k_shade (rounds 1-2)
 	int fused_bounces = 1;         // bounces 1 .. maxBounce-1 of a batch in ONE launch (k_path, path.hpp); ADYPT_FUSED_BOUNCES=0: k_trace + k_shade per bounce
+	int single_fused = 1;          // a single frame runs as a batch of one through the same pipeline (ADYPT_SINGLE_FUSED=0: gen -> [trace -> shade] x maxBounce)
 	int path_blocks = 0, path_lds_depth = 0; // launch geometry of k_path
 	size_t path_lds = 0;
 	uint32_t shade_min = 64;       // deposited hits a wave of k_path waits for before it shades a batch
@@ -804,6 +805,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	if(const char *ov = getenv("ADYPT_GEN_DEAL")) c->deal_chunks = atoi(ov) != 0;
 	if(const char *ov = getenv("ADYPT_FIRST_FUSED")) c->first_fused = atoi(ov) != 0;
 	if(const char *ov = getenv("ADYPT_FUSED_BOUNCES")) c->fused_bounces = atoi(ov) != 0;
+	if(const char *ov = getenv("ADYPT_SINGLE_FUSED")) c->single_fused = atoi(ov) != 0;
 	if(const char *ov = getenv("ADYPT_AUDIT_SELFTEST")) c->audit_selftest = atoi(ov) != 0;
 	if(const char *ov = getenv("ADYPT_SHADE_MIN")) c->shade_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
 	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
@@ -1210,9 +1212,12 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			HIP_TRY(c, hipMemcpyAsync(c->d_sobol, padded, (size_t)m * 64 * sizeof(float), hipMemcpyHostToDevice, c->stream));
 			HIP_TRY(c, hipEventRecord(c->sobol_done[slot], c->stream));
 		}
-		const int use_cache = (m == 1 && n_retrace) ? 0 : 1;
-		f.batched = m > 1 ? 1 : 0;
-		if(m > 1 && n_retrace)
+		// A single frame (no look-ahead, or one frame in flight) runs as a batch of one — camera launch, k_shade_first, k_path, k_resolve: 4 launches
+		// instead of 1 + 2 x maxBounce — whenever a batch would take the one-launch pipeline (ADYPT_SINGLE_FUSED=0: the launch-per-bounce frame)
+		const bool as_batch = m > 1 || (c->single_fused && c->first_fused && c->fused_bounces && !c->sun_visibility && (int64_t)c->n_local_px <= kPathMaxPaths);
+		const int use_cache = (!as_batch && n_retrace) ? 0 : 1;
+		f.batched = as_batch ? 1 : 0;
+		if(as_batch && n_retrace)
 		{
 			// primary-only pass of the re-tracing frames: camera rays -> traversal -> cache image of each frame's group
 			// (on the context's stream, in the whole queue: every sub-batch below starts from these cache images)
@@ -1229,7 +1234,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		const int n_pipes = m > 1 ? std::max(1, std::min(std::min(c->pipeline, kMaxPipes), m)) : 1;
 		// batches start every frame from a cached primary hit: camera rays and bounce 0 in one kernel (k_shade_first) unless the escaped paths
 		// need the sun-visibility queue
-		const bool fused_first = m > 1 && use_cache && !c->sun_visibility && c->first_fused;
+		const bool fused_first = as_batch && use_cache && !c->sun_visibility && c->first_fused;
 		// the counters of all pipes are contiguous: one clearing launch, on the context's stream, before the chains fork
 		clear_counters(c, c->d_counters, n_pipes, c->stream);
 		if(n_pipes > 1)
@@ -1327,7 +1332,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pipes[k].done, 0));
 		}
 		HIP_TRY(c, hipGetLastError());
-		if(m > 1)
+		if(as_batch)
 		{
 			c->batch_spp = c->spp; c->batch_frames = m; c->cache_group = 0;
 			int r = resolve_batch_frames(c, sc, px, 0, hand_out);

@@ -147,7 +147,7 @@ def test_which_batches_take_the_fused_launch(scene_cache):
     p.Trace(True, 6)
     assert p.GetFusedBounces()                      # default on for batches
     p.Trace(True, 1)
-    assert not p.GetFusedBounces()                  # a single frame is traced bounce by bounce (no k_shade_first pass to feed the launch)
+    assert p.GetFusedBounces()                      # a single frame runs as a batch of one through the same four launches
     p.SetSunVisibility(True)
     p.Trace(True, 6)
     assert not p.GetFusedBounces()                  # escaped paths need the sun-visibility queue
@@ -162,6 +162,38 @@ def test_which_batches_take_the_fused_launch(scene_cache):
         inst2 = _instance(scene_cache, "tiny0", 64, 36, {"tmpLifetime": 4, "maxBounce": 5})
     inst2.m_path_tracer.Trace(True, 6)
     assert not inst2.m_path_tracer.GetFusedBounces()
+    with environment(ADYPT_SINGLE_FUSED=0):
+        inst3 = _instance(scene_cache, "tiny0", 64, 36, {"tmpLifetime": 4, "maxBounce": 5})
+    inst3.m_path_tracer.Trace(True, 1)
+    assert not inst3.m_path_tracer.GetFusedBounces()  # ... unless told to keep the launch-per-bounce frame
+    inst3.m_path_tracer.Trace(True, 6)
+    assert inst3.m_path_tracer.GetFusedBounces()
+
+
+@pytest.mark.parametrize("single_fused", [1, 0])
+def test_frame_by_frame_calls_match_oracle_through_either_single_frame_pipeline(single_fused, scene_cache, sobol_matrices):
+    """adypt_trace_spp(ctx, 1) per call without look-ahead (what Instance::Update does): as a batch of one (camera launch, k_shade_first, k_path,
+    k_resolve) or as gen -> [trace -> shade] x maxBounce; frames that re-trace their primaries (every 3rd here) and frames that start from the cache."""
+    pt = {"tmpLifetime": 3, "maxBounce": 5, "subpixel": 2}
+    with environment(ADYPT_SINGLE_FUSED=single_fused):
+        inst = _instance(scene_cache, "tiny0", 104, 70, pt)
+    p = inst.m_path_tracer
+    p.SetLookahead(False)
+    p.SetInstrumentation(counters=True)
+    p.ResetStats()
+    c = inst.m_config.c
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    state = O.PathTracerState(c.width, c.height)
+    shift = O.shift_bytes(31, c.width, c.height)
+    rays = 0
+    for i in range(7):
+        p.Trace(True, 1)
+        assert p.GetFusedBounces() == bool(single_fused)
+        rays += O.pt_frames(osc, P, shift, sobol_matrices, state, 1).as_dict()["rays"]
+        assert np.array_equal(bits(p.ReadResult()), bits(state.accum[..., :3])), i
+        tri, uv = p.ReadHits()
+        assert np.array_equal(tri, state.cache_tri) and np.array_equal(bits(uv), bits(state.cache_uv)), i
+    assert p.GetStats()["rays"] == rays and p.GetSPP() == 7
 
 
 def test_material_zoo_through_the_fused_launch(tmp_path):
