@@ -79,6 +79,8 @@ class BuildInfo(C.Structure):
 _SIGS = {
     # adypt_hip.h
     "adypt_abi_version": (C.c_int, []),
+    "adypt_enable_test_hooks": (C.c_int, [C.c_uint64]),
+    "adypt_test_hooks_enabled": (C.c_int, []),
     "adypt_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(SceneDesc)]),
     "adypt_destroy": (None, [C.c_void_p]),
     "adypt_last_error": (C.c_char_p, [C.c_void_p]),
@@ -117,6 +119,7 @@ _SIGS = {
     "adypt_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int]),
     "adypt_destroy_multi": (None, [C.c_void_p]),
     "adypt_multi_last_error": (C.c_char_p, [C.c_void_p]),
+    "adypt_multi_setup_seconds": (C.c_double, [C.c_void_p, C.c_int]),
     "adypt_multi_device_count": (C.c_int, [C.c_void_p]),
     "adypt_multi_context": (C.c_void_p, [C.c_void_p, C.c_int]),
     "adypt_multi_set_params": (C.c_int, [C.c_void_p, C.POINTER(PtParams)]),
@@ -219,7 +222,7 @@ for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export what the headers declare
     _fn.restype = _res
     _fn.argtypes = _args
-if lib.adypt_abi_version() != 3:
+if lib.adypt_abi_version() != 4:
     raise ImportError("adypt_amd: ABI version mismatch")
 
 

@@ -203,6 +203,17 @@ class WideBVH:
             pass
 
 
+TEST_HOOKS_MAGIC = 0x7465737468303031  # ADYPT_TEST_HOOKS_MAGIC (include/adypt_hip.h)
+
+
+def enable_test_hooks() -> None:
+    """TEST-ONLY (adypt_enable_test_hooks): makes the library honour ADYPT_MULTI_SHARED_DEVICE, ADYPT_COMM_TRANSPORT=host, ADYPT_AUDIT_SELFTEST and
+    ADYPT_GATHER_STALL_TEST for the rest of this process.  tests/conftest.py, tools/comm_world.py and `bench.py --rehearsal` call it; nothing else does."""
+    r = N.lib.adypt_enable_test_hooks(TEST_HOOKS_MAGIC)
+    if r != N.ADYPT_OK:
+        raise RuntimeError("adypt_enable_test_hooks refused")
+
+
 def woop_matrices(triangles: np.ndarray, tri_indices: np.ndarray) -> np.ndarray:
     t = np.ascontiguousarray(triangles).view(np.uint8).reshape(-1)
     idx = np.ascontiguousarray(tri_indices, dtype=np.int32)
@@ -542,6 +553,10 @@ class MultiPathTracer:
         devs = (C.c_int * len(devices))(*devices)
         self._check(N.lib.adypt_create_multi(C.byref(self._m), C.byref(d), devs, len(devices)))
         self.SetConfig(config)
+
+    def SetupSeconds(self, i: int) -> float:
+        """Seconds adypt_create took for devices[i] (the contexts are created concurrently, one host thread each)."""
+        return float(N.lib.adypt_multi_setup_seconds(self._m, i))
 
     def SetConfig(self, config: N.PtParams) -> None:
         self._check(N.lib.adypt_multi_set_params(self._m, C.byref(config)))

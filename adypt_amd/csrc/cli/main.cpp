@@ -40,6 +40,7 @@ int main(int argc, char **argv)
 		else if(a == "--preview" && i + 1 < argc) preview = argv[++i];
 		else if(a == "--fp16") fp16 = 1;
 		else if(a == "--sun-visibility") sun_visibility = 1;
+		else if(a == "--test-hooks") (void)adypt_enable_test_hooks(ADYPT_TEST_HOOKS_MAGIC); // tests only: lets ADYPT_MULTI_SHARED_DEVICE put several shards on one device
 		else if(a == "--primary" && i + 1 < argc) primary = atoi(argv[++i]);
 		else if(a == "--seed" && i + 1 < argc) seed = (unsigned)strtoul(argv[++i], nullptr, 10);
 		else if(a == "--device" && i + 1 < argc) devices.assign(1, atoi(argv[++i]));

@@ -45,6 +45,8 @@ struct HostComm {
 	double timeout_s = 60.0;         // how long a host function waits for a peer before it gives up (ADYPT_HOST_TRANSPORT_TIMEOUT)
 };
 
+inline double &default_timeout_s() { static double t = 60.0; return t; } // set from Tunables::host_transport_timeout_s when the transport is selected (multi.hip)
+
 // waits for the sender to publish; false after timeout_s (the peer died between creating the mailbox and filling it)
 inline bool wait_ready(const Mailbox *m, double timeout_s)
 {
@@ -69,6 +71,9 @@ inline Mailbox *map_box(const std::string &name, size_t bytes, bool create, doub
 	const auto t0 = std::chrono::steady_clock::now();
 	for(;;)
 	{
+		// the reader's clock is checked on EVERY turn, also while the box exists but is not sized yet (a creator that died between
+		// shm_open and ftruncate must not keep the reader here for ever)
+		if(!create && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return nullptr;
 		int fd = shm_open(name.c_str(), create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
 		if(fd >= 0)
 		{
@@ -84,7 +89,6 @@ inline Mailbox *map_box(const std::string &name, size_t bytes, bool create, doub
 			return p == MAP_FAILED ? nullptr : (Mailbox *)p;
 		}
 		if(create) return nullptr;
-		if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return nullptr;
 		std::this_thread::sleep_for(std::chrono::microseconds(200));
 	}
 }
@@ -186,7 +190,7 @@ inline ncclResult_t CommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, 
 	HostComm *c = new HostComm();
 	c->name.assign(id.internal, strnlen(id.internal, NCCL_UNIQUE_ID_BYTES));
 	c->rank = rank; c->nranks = nranks;
-	if(const char *t = getenv("ADYPT_HOST_TRANSPORT_TIMEOUT")) c->timeout_s = std::max(0.1, atof(t));
+	c->timeout_s = default_timeout_s();
 	*comm = (ncclComm_t)c;
 	return ncclSuccess;
 }

@@ -11,16 +11,24 @@
 // holds an RCCL (e.g. the copy PyTorch ships) shares that one instead of bringing a second.
 #include "ctx_access.hpp"
 #include "host_transport.hpp"
+#include "tunables.hpp"
 #include "../../../include/adypt_hip.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 using namespace adypt;
@@ -52,20 +60,21 @@ RcclApi *rccl(std::string *err)
 {
 	std::lock_guard<std::mutex> lock(g_rccl_mutex);
 	if(g_rccl.handle) return &g_rccl;
-	if(const char *tr = getenv("ADYPT_COMM_TRANSPORT"))
-		if(!strcmp(tr, "host"))
-		{	// TEST HOOK (host_transport.hpp): the same calls, carried through shared memory, so that N ranks can share one device
-			namespace ht = adypt_host_transport;
-			RcclApi a;
-			a.handle = (void *)&g_rccl; a.path = "host transport (test hook)";
-			a.GetUniqueId = ht::GetUniqueId; a.CommInitRank = ht::CommInitRank; a.CommInitAll = ht::CommInitAll; a.CommDestroy = ht::CommDestroy;
-			a.Send = ht::Send; a.Recv = ht::Recv; a.AllReduce = ht::AllReduce; a.GroupStart = ht::GroupStart; a.GroupEnd = ht::GroupEnd;
-			a.GetErrorString = ht::GetErrorString;
-			g_rccl = a;
-			return &g_rccl;
-		}
+	const Tunables tun = read_tunables();
+	if(tun.comm_transport_host)
+	{	// TEST HOOK (host_transport.hpp; only after adypt_enable_test_hooks): the same calls, carried through shared memory, so that N ranks can share one device
+		namespace ht = adypt_host_transport;
+		RcclApi a;
+		a.handle = (void *)&g_rccl; a.path = "host transport (test hook)";
+		a.GetUniqueId = ht::GetUniqueId; a.CommInitRank = ht::CommInitRank; a.CommInitAll = ht::CommInitAll; a.CommDestroy = ht::CommDestroy;
+		a.Send = ht::Send; a.Recv = ht::Recv; a.AllReduce = ht::AllReduce; a.GroupStart = ht::GroupStart; a.GroupEnd = ht::GroupEnd;
+		a.GetErrorString = ht::GetErrorString;
+		if(tun.host_transport_timeout_s > 0.0) ht::default_timeout_s() = tun.host_transport_timeout_s;
+		g_rccl = a;
+		return &g_rccl;
+	}
 	std::vector<std::pair<std::string, int>> tries;
-	if(const char *ov = getenv("ADYPT_RCCL_LIB")) tries.push_back({ov, RTLD_NOW | RTLD_LOCAL});
+	if(!tun.rccl_lib.empty()) tries.push_back({tun.rccl_lib, RTLD_NOW | RTLD_LOCAL});
 	tries.push_back({"librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD});
 	tries.push_back({"librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD});
 	tries.push_back({"librccl.so.1", RTLD_NOW | RTLD_LOCAL});
@@ -139,6 +148,53 @@ void free_comm(void *p)
 		if(r_ != ncclSuccess) { ctx_set_error((ctx), std::string(#expr) + ": " + (api)->GetErrorString(r_)); return ADYPT_E_HIP; } \
 	} while(0)
 
+// Bounds the one exchange of the data path.  A collective whose peer never arrives does not return and cannot be cancelled (the streams are
+// blocked behind it); the only safe way out of a process that has touched the GPU is to END it — never to re-exec it.  So: a thread that, if the
+// gather has not finished within ADYPT_GATHER_TIMEOUT seconds (default 120, 0 = no watchdog), prints where the gather stands and the state of
+// every rank's stream to stderr and exits the process with code 86.  Armed around the RCCL calls and the drains that follow them, nothing else.
+class GatherWatchdog {
+public:
+	GatherWatchdog(double timeout_s, std::function<std::string()> state) : stage_("start")
+	{
+		if(!(timeout_s > 0.0)) return;
+		thread_ = std::thread([this, timeout_s, state] {
+			std::unique_lock<std::mutex> lock(m_);
+			if(cv_.wait_for(lock, std::chrono::duration<double>(timeout_s), [this] { return done_; })) return;
+			fprintf(stderr, "[adypt] gather watchdog: the radiance gather has not finished after %.1f s (stage: %s)\n%s[adypt] exiting the process with code 86 (a collective cannot be cancelled)\n",
+					timeout_s, stage_.load(), state().c_str());
+			fflush(stderr);
+			_exit(86);
+		});
+	}
+	~GatherWatchdog()
+	{
+		if(!thread_.joinable()) return;
+		{ std::lock_guard<std::mutex> lock(m_); done_ = true; }
+		cv_.notify_all();
+		thread_.join();
+	}
+	void stage(const char *s) { stage_.store(s); }
+private:
+	std::mutex m_;
+	std::condition_variable cv_;
+	bool done_ = false;
+	std::atomic<const char *> stage_;
+	std::thread thread_;
+};
+const char *stream_state(int device, hipStream_t stream)
+{
+	if(hipSetDevice(device) != hipSuccess) return "device not reachable";
+	const hipError_t q = hipStreamQuery(stream);
+	return q == hipSuccess ? "idle" : q == hipErrorNotReady ? "busy" : hipGetErrorString(q);
+}
+// TEST HOOK (ADYPT_GATHER_STALL_TEST=1 after adypt_enable_test_hooks): the gather never proceeds — what a lost peer looks like to the caller
+void stall_if_asked(const Tunables &tun, GatherWatchdog &wd)
+{
+	if(!tun.gather_stall_test) return;
+	wd.stage("stalled by ADYPT_GATHER_STALL_TEST");
+	for(;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+}
+
 // buffers of a communicator whose ncclComm_t already exists
 int finish_comm(adypt_ctx *ctx, Comm *k)
 {
@@ -193,6 +249,8 @@ struct adypt_multi {
 	bool comms_ready = false;
 	bool shared_device = false; // test hook (ADYPT_MULTI_SHARED_DEVICE=1): several shards on ONE device; the exchange is a device copy
 	int spp = 0;
+	std::vector<double> setup_s; // seconds adypt_create took per device (they run concurrently)
+	Tunables tun;
 };
 
 namespace {
@@ -240,30 +298,47 @@ int adypt_create_multi(adypt_multi **out, const adypt_scene_desc *desc, const in
 	g_multi_error.clear();
 	if(!out || !desc || !device_ids || n_dev < 1 || n_dev > 64) { g_multi_error = "adypt_create_multi: bad arguments"; return ADYPT_E_INVALID; }
 	*out = nullptr;
-	// RCCL refuses two ranks on one device.  ADYPT_MULTI_SHARED_DEVICE=1 is a test hook for boxes with a single GPU: the same fan-out,
+	// RCCL refuses two ranks on one device.  ADYPT_MULTI_SHARED_DEVICE=1 (after adypt_enable_test_hooks) is a test hook for boxes with a single GPU: the same fan-out,
 	// sharding, ordering and un-tiling, with the peer -> root transfers done by device-to-device copies instead of ncclSend / ncclRecv.
-	const char *shared_env = getenv("ADYPT_MULTI_SHARED_DEVICE");
-	const bool shared = shared_env && atoi(shared_env) != 0;
+	const Tunables tun = read_tunables();
+	const bool shared = tun.multi_shared_device; // (false unless adypt_enable_test_hooks was called)
 	for(int i = 0; i < n_dev; ++i)
 		for(int j = 0; j < i; ++j)
 			if(device_ids[i] == device_ids[j] && !shared) { g_multi_error = "adypt_create_multi: device listed twice (RCCL needs distinct devices)"; return ADYPT_E_INVALID; }
 	adypt_multi *m = new adypt_multi();
 	m->shared_device = shared;
-	for(int i = 0; i < n_dev; ++i)
-	{
+	m->tun = tun;
+	// One host thread per device: each context is an upload of the whole scene (80 MB .. 2.7 GB) plus its own allocations, and the devices
+	// do not share a PCIe link — created one after the other, an 8-GPU start-up took 8 x the 1-GPU time.  (Several shards on ONE device, the
+	// test hook, are created in turn: they would only queue up behind each other on the device's legacy stream.)
+	std::vector<adypt_ctx *> made((size_t)n_dev, nullptr);
+	std::vector<int> rc((size_t)n_dev, ADYPT_OK);
+	std::vector<std::string> why((size_t)n_dev);
+	m->setup_s.assign((size_t)n_dev, 0.0);
+	auto create_one = [&](int i) {
+		const auto t0 = std::chrono::steady_clock::now();
 		adypt_scene_desc d = *desc;
 		d.device = device_ids[i]; d.tile_rank = i; d.tile_nranks = n_dev;
-		adypt_ctx *c = nullptr;
-		const int r = adypt_create(&c, &d);
-		if(r != ADYPT_OK)
-		{
-			g_multi_error = std::string("device ") + std::to_string(device_ids[i]) + ": " + adypt_last_error(nullptr);
-			adypt_destroy_multi(m);
-			return r;
-		}
-		m->ctx.push_back(c);
-		m->devices.push_back(device_ids[i]);
+		rc[(size_t)i] = adypt_create(&made[(size_t)i], &d);
+		if(rc[(size_t)i] != ADYPT_OK) why[(size_t)i] = adypt_last_error(nullptr); // (thread-local: read on the thread that failed)
+		m->setup_s[(size_t)i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	};
+	if(shared || n_dev == 1) for(int i = 0; i < n_dev; ++i) create_one(i);
+	else
+	{
+		std::vector<std::thread> workers;
+		for(int i = 0; i < n_dev; ++i) workers.emplace_back(create_one, i);
+		for(std::thread &t : workers) t.join();
 	}
+	for(int i = 0; i < n_dev; ++i)
+		if(rc[(size_t)i] != ADYPT_OK)
+		{
+			g_multi_error = std::string("device ") + std::to_string(device_ids[i]) + ": " + why[(size_t)i];
+			for(adypt_ctx *c : made) adypt_destroy(c); // (null-safe)
+			delete m;
+			return rc[(size_t)i];
+		}
+	for(int i = 0; i < n_dev; ++i) { m->ctx.push_back(made[(size_t)i]); m->devices.push_back(device_ids[i]); }
 	*out = m;
 	return ADYPT_OK;
 }
@@ -276,6 +351,7 @@ void adypt_destroy_multi(adypt_multi *m)
 }
 
 int adypt_multi_device_count(const adypt_multi *m) { return m ? (int)m->ctx.size() : ADYPT_E_INVALID; }
+double adypt_multi_setup_seconds(const adypt_multi *m, int i) { return (m && i >= 0 && i < (int)m->setup_s.size()) ? m->setup_s[(size_t)i] : -1.0; }
 adypt_ctx *adypt_multi_context(adypt_multi *m, int i) { return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[(size_t)i] : nullptr; }
 
 #define FOR_ALL(m, call)                                                \
@@ -303,7 +379,7 @@ int adypt_multi_get_stats(adypt_multi *m, adypt_stats *out)
 		if(r != ADYPT_OK) return mfail_ctx(m, r, c);
 		// counts add up over the devices; the devices run concurrently, so times are the slowest device's
 		out->rays += s.rays; out->nodes_visited += s.nodes_visited; out->tris_tested += s.tris_tested; out->hits += s.hits; out->shaded += s.shaded;
-		out->stack_overflows += s.stack_overflows; out->bad_materials += s.bad_materials;
+		out->stack_overflows += s.stack_overflows; out->bad_materials += s.bad_materials; out->audit_errors += s.audit_errors;
 		out->path_rays += s.path_rays; out->path_nodes += s.path_nodes; out->path_tris += s.path_tris; out->path_hits += s.path_hits; out->path_shaded += s.path_shaded;
 		out->max_stack = std::max(out->max_stack, s.max_stack); out->trace_launches = std::max(out->trace_launches, s.trace_launches);
 		out->trace_ms = std::max(out->trace_ms, s.trace_ms); out->shade_ms = std::max(out->shade_ms, s.shade_ms);
@@ -370,6 +446,16 @@ int adypt_multi_gather_radiance(adypt_multi *m, void **rgb_device)
 		if(r != ADYPT_OK) return r;
 	}
 	Comm *k0 = comm_of(root);
+	GatherWatchdog wd(n > 1 ? m->tun.gather_timeout_s : 0.0, [m] {
+		std::string s;
+		for(size_t i = 0; i < m->ctx.size(); ++i)
+		{
+			const CtxInfo ci = ctx_info(m->ctx[i]);
+			s += "[adypt]   rank " + std::to_string(i) + " (device " + std::to_string(ci.device) + ", " + std::to_string(ci.n_local_px) + " local pixels): stream " + stream_state(ci.device, ci.stream) + "\n";
+		}
+		return s;
+	});
+	if(n > 1) stall_if_asked(m->tun, wd);
 	if(n > 1 && m->shared_device)
 	{
 		for(int r = 1; r < n; ++r)
@@ -387,6 +473,7 @@ int adypt_multi_gather_radiance(adypt_multi *m, void **rgb_device)
 	{
 		// the one exchange: grouped point-to-point = ncclGather with exact per-rank sizes; peer r -> root over its own link
 		RcclApi *api = k0->api;
+		wd.stage("ncclGroupStart .. ncclGroupEnd (grouped ncclSend / ncclRecv)");
 		ncclResult_t gr = api->GroupStart();
 		if(gr != ncclSuccess) return mfail(m, ADYPT_E_HIP, std::string("ncclGroupStart: ") + api->GetErrorString(gr));
 		ncclResult_t bad = ncclSuccess;
@@ -406,8 +493,10 @@ int adypt_multi_gather_radiance(adypt_multi *m, void **rgb_device)
 		if(bad != ncclSuccess || gr != ncclSuccess)
 			return mfail(m, ADYPT_E_HIP, std::string("RCCL gather: ") + api->GetErrorString(bad != ncclSuccess ? bad : gr));
 	}
+	wd.stage("un-tiling on the root (drains the root's stream: the receives)");
 	int r = assemble_on_root(root, k0);
 	if(r != ADYPT_OK) return mfail_ctx(m, r, root);
+	wd.stage("draining the peers' streams (their sends)");
 	// the peers' sends complete with the root's receives; drain their streams so their images may be overwritten again
 	for(int i = 1; i < n; ++i) { int w = adypt_wait(m->ctx[(size_t)i]); if(w != ADYPT_OK) return mfail_ctx(m, w, m->ctx[(size_t)i]); }
 	*rgb_device = k0->rgb;
@@ -476,9 +565,16 @@ int adypt_comm_gather_radiance(adypt_ctx *ctx, void **rgb_device)
 		if(r != ADYPT_OK) return r;
 	}
 	HIP_OK(ctx, hipSetDevice(i.device));
+	const Tunables tun = read_tunables();
+	GatherWatchdog wd(i.nranks > 1 ? tun.gather_timeout_s : 0.0, [i] {
+		return "[adypt]   rank " + std::to_string(i.rank) + " of " + std::to_string(i.nranks) + " (device " + std::to_string(i.device) + ", " + std::to_string(i.n_local_px) + " local pixels): stream " +
+			   stream_state(i.device, i.stream) + "\n";
+	});
+	if(i.nranks > 1) stall_if_asked(tun, wd);
 	if(i.nranks > 1)
 	{
 		RcclApi *api = k->api;
+		wd.stage("ncclGroupStart .. ncclGroupEnd (grouped ncclSend / ncclRecv)");
 		NCCL_OK(ctx, api, api->GroupStart());
 		ncclResult_t bad = ncclSuccess;
 		if(i.rank == 0)
@@ -497,11 +593,13 @@ int adypt_comm_gather_radiance(adypt_ctx *ctx, void **rgb_device)
 	}
 	if(i.rank == 0)
 	{
+		wd.stage("un-tiling on the root (drains the root's stream: the receives)");
 		int r = assemble_on_root(ctx, k);
 		if(r != ADYPT_OK) return r;
 		*rgb_device = k->rgb;
 		return ADYPT_OK;
 	}
+	wd.stage("draining this rank's stream (its send)");
 	return adypt_wait(ctx); // the send has left the accumulation image
 }
 

@@ -19,7 +19,8 @@
 //     atomic per shading round, issued BEFORE the gathers for the paths that are certain to end (miss, last bounce) so that its latency is hidden;
 //   * the hit's triangle record is looked up by REFERENCE index (the traversal's own index: SceneArgs::triangles here is the per-reference copy
 //     of the records, made once at upload), so the uTriIndices remap (traversal.glsl:253-254) — a dependent load in front of every deposit —
-//     disappears from this kernel; the triangle id itself is never an output of these bounces;
+//     disappears from this kernel; the triangle id itself is never an output of these bounces.  A context without that copy (too large, or
+//     the allocation failed) passes uTriIndices as PathArgs::tri_remap and the shading round applies it;
 //   * no inter-workgroup communication of any kind, so none of the cross-XCD visibility questions of a streaming queue.
 // The kernel ends when the global queue is dry and every workgroup has finished the paths it holds.
 #pragma once
@@ -50,6 +51,7 @@ struct PathArgs {
 	const float4 *woop;
 	const float *in_o; const float4 *in_d; const float *in_col; // the batch's ray queue as k_shade_first leaves it (12 / 16 / 12 bytes per path)
 	RayStats *ray_stats;           // always null (traverse_trip.inc's per-ray record belongs to adypt_trace_rays)
+	const int32_t *tri_remap;      // null: SceneArgs::triangles is the per-reference copy; else uTriIndices, applied in the shading round (traversal.glsl:253-254)
 	const uint32_t *count;         // paths per queue segment: count[s * kCursorStride]
 	uint32_t *cursor;              // fetch cursor per segment, zero at launch
 	uint2 *spill;                  // [(stack_size - lds_depth)][total lanes]
@@ -342,6 +344,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 						}
 						else
 						{
+							if(a.tri_remap) tri_idx = a.tri_remap[tri_idx]; // (contexts without the per-reference copy of the triangle records)
 							const SurfaceInfo si = fetch_info(f, sc, tri_idx, tu, tv);
 							origin = si.origin;
 							if(si.bad_mat) { alive = false; bad_mat = true; }

@@ -13,10 +13,12 @@
 #include "traverse.hpp"
 #include "path.hpp"
 #include "ctx_access.hpp"
+#include "tunables.hpp"
 #include "../../../include/adypt_hip.h"
 #include "../../../include/adypt_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +32,7 @@ namespace {
 constexpr int kMaxBounce = 32;
 constexpr int kMaxFramesInFlight = 128;
 constexpr int kMaxPipes = 4;           // sub-batches of a batch that run as concurrent chains (adypt_set_pipeline)
+constexpr long kRefTrianglesAutoMaxMB = 1l << 20; // ADYPT_REF_TRIANGLES_MAX_MB unset: the per-reference triangle copy is made whatever its size
 constexpr int kDefaultPipes = 1;       // measured: a second chain overlaps but recovers nothing (profiles/r3_ablations_k_trace.txt)
 
 struct FrameCounters {                 // one memset per frame; every counter on its own 128-byte line
@@ -59,7 +62,7 @@ __global__ void k_audit_poison(float4 *out_d, size_t n, uint32_t *seen, size_t n
 	if(i < n) out_d[i].w = __uint_as_float(kAuditPoison);
 	if(i < n_seen) seen[i] = 0u;
 }
-__global__ void k_audit_check(const float4 *out_d, const uint32_t *count, uint32_t seg_cap, uint32_t *seen, unsigned long long *errors)
+__global__ void k_audit_check(const float4 *out_d, const uint32_t *count, uint32_t seg_cap, uint32_t *seen, uint32_t id_limit, unsigned long long *errors)
 {
 	const uint32_t seg = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
 	if(i >= seg_cap) return;
@@ -68,7 +71,8 @@ __global__ void k_audit_check(const float4 *out_d, const uint32_t *count, uint32
 	if(i < count[seg * kCursorStride])
 	{
 		const uint32_t id = w & kPathIdMask;
-		bad = w == kAuditPoison || ((atomicOr(&seen[id >> 5], 1u << (id & 31u)) >> (id & 31u)) & 1u); // never written, or a path that holds two slots
+		// never written, a path id the bitmap has no bit for (a corrupted word: counted, the bitmap is not touched), or a path that holds two slots
+		bad = w == kAuditPoison || id >= id_limit || ((atomicOr(&seen[id >> 5], 1u << (id & 31u)) >> (id & 31u)) & 1u);
 	}
 	else bad = w != kAuditPoison;                                                                     // written beyond what the counter admits
 	if(bad) atomicAdd(errors, 1ull);
@@ -99,11 +103,12 @@ struct adypt_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	std::string error;
+	Tunables tun;              // the environment as adypt_create found it (tunables.hpp)
 
 	// scene (immutable after create)
 	void *d_nodes = nullptr, *d_woop = nullptr, *d_tri_indices = nullptr, *d_triangles = nullptr, *d_materials = nullptr, *d_tri_class = nullptr;
 	void *d_texels = nullptr, *d_local_blocks = nullptr;
-	void *d_ref_triangles = nullptr;          // k_path: the triangle records once per REFERENCE (uTriIndices order), made on the device at the first fused batch
+	void *d_ref_triangles = nullptr;          // k_path: the triangle records once per REFERENCE (uTriIndices order), made at adypt_create; null = k_path remaps through d_tri_indices
 	void *d_all_blocks = nullptr;             // adypt_assemble_radiance: block lists of all ranks
 	std::vector<int64_t> all_blocks_offset;
 	int64_t n_nodes = 0, n_refs = 0, n_tris = 0, n_mats = 0;
@@ -156,6 +161,7 @@ struct adypt_ctx {
 
 	// launch geometry of the persistent traversal kernel
 	int num_cus = 0, trace_blocks = 0, lds_depth = 0, occupancy_api = 0;
+	size_t lds_per_cu = (size_t)160 * 1024; // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor
 	uint32_t refill_min = kRefillMin, chunk = kChunk, bite = kBite, endgame = kEndgame;
 	// Camera rays come in queue order = 8x8 pixel tiles, so a wave's rays are coherent and finish together: a wave takes a WHOLE tile when all its
 	// lanes are idle (refill threshold 64, bites of 64 from the workgroup's reservation) and its lanes then walk the same nodes.  Measured (round 4,
@@ -332,7 +338,7 @@ int configure_trace(adypt_ctx *c, int stack_size)
 {
 	c->lds_depth = std::max(1, std::min(stack_size, kLdsStackMax));
 	// testing / tuning hook: a smaller LDS part pushes stack entries into the global spill array (tests cover that path)
-	if(const char *ov = getenv("ADYPT_LDS_STACK_DEPTH")) c->lds_depth = std::max(1, std::min(c->lds_depth, atoi(ov)));
+	if(c->tun.lds_stack_depth > 0) c->lds_depth = std::max(1, std::min(c->lds_depth, c->tun.lds_stack_depth));
 	size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2) + sizeof(WgPool); // stacks + the workgroup's ray pool
 	int per_cu = 0;
 	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
@@ -343,35 +349,37 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	// the others' from the caches: a BVH beyond the 256 MB Infinity Cache keeps 5
 	const size_t bvh_bytes = (size_t)c->n_nodes * 80 + (size_t)c->n_refs * 52;
 	if(bvh_bytes > ((size_t)256 << 20)) per_cu = std::min(per_cu, 5);
-	if(const char *ov = getenv("ADYPT_TRACE_BLOCKS_PER_CU")) // tuning override
+	if(c->tun.trace_blocks_per_cu > 0) // tuning override
 	{
-		const int want = std::max(1, std::min(16, atoi(ov)));
+		const int want = c->tun.trace_blocks_per_cu;
 		// Fewer workgroups per CU than the registers allow: the traversal launches of two pipes overlap, and together they would
 		// fill the CU again — so the launch asks for as much LDS as makes `want` workgroups the most that fit in a CU's 160 KB
-		if(want < per_cu) lds = std::max(lds, std::min<size_t>(64 * 1024, (((size_t)160 * 1024 - 2048) / (size_t)want) & ~(size_t)1023));
+		if(want < per_cu) lds = std::max(lds, std::min<size_t>(64 * 1024, ((c->lds_per_cu - 2048) / (size_t)want) & ~(size_t)1023));
 		per_cu = want;
 	}
 	c->lds_bytes = lds;
 	c->trace_blocks = c->num_cus * per_cu;
 	// k_path (path.hpp): as many workgroups per CU as its registers allow, with the deepest LDS stack that still fits next to the path table
 	{
-		int want = 6, got = 0, depth = 1;
-		if(const char *ov = getenv("ADYPT_PATH_BLOCKS_PER_CU")) want = std::max(1, std::min(8, atoi(ov)));
-		for(; want >= 1 && got < want; --want)
+		const int want0 = c->tun.path_blocks_per_cu > 0 ? c->tun.path_blocks_per_cu : 6;
+		const size_t fixed = path_lds_bytes(0), per_entry = (size_t)(kTraceThreads / 64) * 64 * sizeof(uint2);
+		int chosen = 0, depth = 1;
+		for(int want = want0; want >= 1 && !chosen; --want)
 		{
 			// LDS is handed out in granules; the occupancy query does not know: measured, it answers 6 for 26944 bytes per workgroup, of which a
-			// compute unit then runs 5 at a time (the sixth of every six waits for a slot: -5 %).  So the budget is whole KiB of 160 / want.
-			const size_t budget = ((size_t)160 / (size_t)want) * 1024, fixed = path_lds_bytes(0), per_entry = (size_t)(kTraceThreads / 64) * 64 * sizeof(uint2);
+			// compute unit then runs 5 at a time (the sixth of every six waits for a slot: -5 %).  So the budget is whole KiB of (LDS per CU) / want.
+			const size_t budget = std::min<size_t>(((c->lds_per_cu / 1024) / (size_t)want) * 1024, 64 * 1024);
 			if(budget < fixed + per_entry) continue;
-			depth = (int)std::min<size_t>((size_t)std::min(stack_size, kLdsStackMax), (budget - fixed) / per_entry);
-			if(const char *ov = getenv("ADYPT_PATH_LDS_DEPTH")) depth = std::max(1, std::min(depth, atoi(ov)));
-			HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, k_path<false>, kTraceThreads, path_lds_bytes(depth)));
-			if(got >= want) break;
+			int d = (int)std::min<size_t>((size_t)std::min(stack_size, kLdsStackMax), (budget - fixed) / per_entry);
+			if(c->tun.path_lds_depth > 0) d = std::max(1, std::min(d, c->tun.path_lds_depth));
+			int got = 0; // the query is made with THIS want's depth, and judged against this want
+			HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, k_path<false>, kTraceThreads, path_lds_bytes(d)));
+			if(got >= want) { chosen = want; depth = d; }
 		}
-		if(want < 1) return fail(c, ADYPT_E_HIP, "k_path does not fit a compute unit");
+		if(!chosen) return fail(c, ADYPT_E_HIP, "k_path does not fit a compute unit");
 		c->path_lds_depth = depth; c->path_lds = path_lds_bytes(depth);
-		c->path_blocks = c->num_cus * want;
-		if(getenv("ADYPT_PATH_VERBOSE")) fprintf(stderr, "[adypt] k_path: %d workgroups per CU, %d path slots each, LDS stack depth %d, %zu bytes of LDS\n", want, kPathSlots, depth, c->path_lds);
+		c->path_blocks = c->num_cus * chosen;
+		if(c->tun.path_verbose) fprintf(stderr, "[adypt] k_path: %d workgroups per CU, %d path slots each, LDS stack depth %d, %zu bytes of LDS\n", chosen, kPathSlots, depth, c->path_lds);
 	}
 	return ensure_spill(c, stack_size);
 }
@@ -384,6 +392,7 @@ int launch_path(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int pari
 	a.nodes = (const uint4 *)c->d_nodes; a.woop = (const float4 *)c->d_woop;
 	a.in_o = (const float *)c->q_o[parity] + 3 * win.offset; a.in_d = c->q_d[parity] + win.offset; a.in_col = (const float *)c->q_col[parity] + 3 * win.offset;
 	a.ray_stats = nullptr;
+	a.tri_remap = c->d_ref_triangles ? nullptr : (const int32_t *)c->d_tri_indices;
 	a.count = count; a.cursor = cursor;
 	a.spill = pipe.spill; a.stats = c->d_stats;
 	a.seg_cap = win.seg_cap;
@@ -669,7 +678,7 @@ void audit_after(adypt_ctx *c, const QueueArgs &q, hipStream_t stream, int pipe 
 	if(!(c->instrumentation & 4) || !c->d_audit_seen || c->audit_words * 32 < c->alloc_slots) return;
 	if(c->audit_selftest) hipLaunchKernelGGL(k_audit_plant, dim3(1), dim3(1), 0, stream, q.out_d, (const uint32_t *)q.count_out);
 	hipLaunchKernelGGL(k_audit_check, dim3((q.seg_cap + 255) / 256, kNumSegments), dim3(256), 0, stream, (const float4 *)q.out_d, (const uint32_t *)q.count_out, q.seg_cap, c->d_audit_seen + (size_t)pipe * c->audit_words,
-					   &c->d_stats->audit_errors);
+					   (uint32_t)std::min<size_t>(c->audit_words * 32, 0xffffffffu), &c->d_stats->audit_errors);
 }
 
 int ensure_ray_stats(adypt_ctx *c)
@@ -725,6 +734,48 @@ inline void drop_lookahead(adypt_ctx *c) { c->ahead_count = 0; c->ahead_pos = 0;
 }  // namespace
 
 namespace adypt {
+
+namespace { std::atomic<bool> g_test_hooks{false}; }
+bool test_hooks_enabled() { return g_test_hooks.load(std::memory_order_acquire); }
+
+// The one place of csrc/device that reads the environment (tunables.hpp has the table).
+Tunables read_tunables()
+{
+	Tunables t;
+	auto num = [](const char *name, long lo, long hi, long unset) -> long {
+		const char *v = getenv(name);
+		if(!v || !*v) return unset;
+		char *end = nullptr;
+		const long x = strtol(v, &end, 10);
+		if(end == v) return unset;
+		return std::max(lo, std::min(hi, x));
+	};
+	auto flag = [&](const char *name, int unset) -> int { return num(name, 0, 1 << 30, unset) != 0 ? 1 : 0; };
+	t.frames_in_flight = (int)num("ADYPT_FRAMES_IN_FLIGHT", 1, kMaxFramesInFlight, 0);
+	t.pipeline = (int)num("ADYPT_PIPELINE", 1, kMaxPipes, kDefaultPipes);
+	t.fused_bounces = flag("ADYPT_FUSED_BOUNCES", 1); t.first_fused = flag("ADYPT_FIRST_FUSED", 1); t.single_fused = flag("ADYPT_SINGLE_FUSED", 1);
+	t.gen_deal = flag("ADYPT_GEN_DEAL", 1); t.shade_bin = flag("ADYPT_SHADE_BIN", 0);
+	t.refill_min = (int)num("ADYPT_REFILL_MIN", 1, 64, 0); t.refill_min_primary = (int)num("ADYPT_REFILL_MIN_PRIMARY", 1, 64, 0);
+	t.bite = (int)num("ADYPT_BITE", 1, 4096, 0); t.bite_primary = (int)num("ADYPT_BITE_PRIMARY", 1, 4096, 0);
+	t.chunk = (int)num("ADYPT_CHUNK", 16, 4096, 0); t.endgame = (int)num("ADYPT_ENDGAME", 0, 1024, -1);
+	t.shade_min = (int)num("ADYPT_SHADE_MIN", 1, 64, 0);
+	t.lds_stack_depth = (int)num("ADYPT_LDS_STACK_DEPTH", 1, kLdsStackMax, 0); t.trace_blocks_per_cu = (int)num("ADYPT_TRACE_BLOCKS_PER_CU", 1, 16, 0);
+	t.path_blocks_per_cu = (int)num("ADYPT_PATH_BLOCKS_PER_CU", 1, 8, 0); t.path_lds_depth = (int)num("ADYPT_PATH_LDS_DEPTH", 1, kLdsStackMax, 0);
+	t.path_verbose = flag("ADYPT_PATH_VERBOSE", 0);
+	t.ref_triangles_max_mb = num("ADYPT_REF_TRIANGLES_MAX_MB", 0, 1 << 20, -1);
+	if(const char *v = getenv("ADYPT_RCCL_LIB")) t.rccl_lib = v;
+	if(const char *v = getenv("ADYPT_GATHER_TIMEOUT")) { const double x = atof(v); t.gather_timeout_s = x >= 0.0 && x <= 86400.0 ? x : t.gather_timeout_s; }
+	if(test_hooks_enabled())
+	{
+		t.multi_shared_device = flag("ADYPT_MULTI_SHARED_DEVICE", 0) != 0;
+		t.audit_selftest = flag("ADYPT_AUDIT_SELFTEST", 0) != 0;
+		t.gather_stall_test = flag("ADYPT_GATHER_STALL_TEST", 0) != 0;
+		if(const char *v = getenv("ADYPT_COMM_TRANSPORT")) t.comm_transport_host = !strcmp(v, "host");
+		if(const char *v = getenv("ADYPT_HOST_TRANSPORT_TIMEOUT")) t.host_transport_timeout_s = std::max(0.1, atof(v));
+	}
+	return t;
+}
+
 CtxInfo ctx_info(adypt_ctx *c)
 {
 	CtxInfo i;
@@ -739,6 +790,14 @@ void **ctx_comm_slot(adypt_ctx *c, void (***free_fn)(void *)) { *free_fn = &c->c
 extern "C" {
 
 int adypt_abi_version(void) { return ADYPT_ABI_VERSION; }
+
+int adypt_enable_test_hooks(uint64_t magic)
+{
+	if(magic != ADYPT_TEST_HOOKS_MAGIC) return ADYPT_E_INVALID;
+	g_test_hooks.store(true, std::memory_order_release);
+	return ADYPT_OK;
+}
+int adypt_test_hooks_enabled(void) { return test_hooks_enabled() ? 1 : 0; }
 
 const char *adypt_last_error(const adypt_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
@@ -796,22 +855,24 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	for(int k = 1; k < kMaxPipes; ++k) HIP_CREATE(hipStreamCreateWithFlags(&c->pipes[k].stream, hipStreamNonBlocking));
 	for(int k = 0; k < kMaxPipes; ++k) HIP_CREATE(hipEventCreateWithFlags(&c->pipes[k].done, hipEventDisableTiming));
 	HIP_CREATE(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
-	if(const char *ov = getenv("ADYPT_PIPELINE")) c->pipeline = std::max(1, std::min(kMaxPipes, atoi(ov)));
+	c->tun = read_tunables();
+	c->pipeline = c->tun.pipeline;
 	hipDeviceProp_t prop;
 	HIP_CREATE(hipGetDeviceProperties(&prop, c->device));
 	c->num_cus = prop.multiProcessorCount;
-	if(const char *ov = getenv("ADYPT_REFILL_MIN")) c->refill_min = c->refill_min_primary = (uint32_t)std::max(1, std::min(64, atoi(ov)));
-	if(const char *ov = getenv("ADYPT_REFILL_MIN_PRIMARY")) c->refill_min_primary = (uint32_t)std::max(1, std::min(64, atoi(ov)));
-	if(const char *ov = getenv("ADYPT_GEN_DEAL")) c->deal_chunks = atoi(ov) != 0;
-	if(const char *ov = getenv("ADYPT_FIRST_FUSED")) c->first_fused = atoi(ov) != 0;
-	if(const char *ov = getenv("ADYPT_FUSED_BOUNCES")) c->fused_bounces = atoi(ov) != 0;
-	if(const char *ov = getenv("ADYPT_SINGLE_FUSED")) c->single_fused = atoi(ov) != 0;
-	if(const char *ov = getenv("ADYPT_AUDIT_SELFTEST")) c->audit_selftest = atoi(ov) != 0;
-	if(const char *ov = getenv("ADYPT_SHADE_MIN")) c->shade_min = (uint32_t)std::max(1, std::min(64, atoi(ov)));
-	if(const char *ov = getenv("ADYPT_CHUNK")) c->chunk = (uint32_t)std::max(16, std::min(4096, atoi(ov)));
-	if(const char *ov = getenv("ADYPT_ENDGAME")) c->endgame = (uint32_t)std::max(0, std::min(1024, atoi(ov)));
-	if(const char *ov = getenv("ADYPT_BITE")) c->bite = c->bite_primary = (uint32_t)std::max(1, std::min(4096, atoi(ov)));
-	if(const char *ov = getenv("ADYPT_BITE_PRIMARY")) c->bite_primary = (uint32_t)std::max(1, std::min(4096, atoi(ov)));
+	if(prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) c->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+	{
+		const Tunables &t = c->tun;
+		if(t.refill_min > 0) c->refill_min = c->refill_min_primary = (uint32_t)t.refill_min;
+		if(t.refill_min_primary > 0) c->refill_min_primary = (uint32_t)t.refill_min_primary;
+		c->deal_chunks = t.gen_deal; c->first_fused = t.first_fused; c->fused_bounces = t.fused_bounces; c->single_fused = t.single_fused;
+		c->audit_selftest = t.audit_selftest;
+		if(t.shade_min > 0) c->shade_min = (uint32_t)t.shade_min;
+		if(t.chunk > 0) c->chunk = (uint32_t)t.chunk;
+		if(t.endgame >= 0) c->endgame = (uint32_t)t.endgame;
+		if(t.bite > 0) c->bite = c->bite_primary = (uint32_t)t.bite;
+		if(t.bite_primary > 0) c->bite_primary = (uint32_t)t.bite_primary;
+	}
 
 	c->n_nodes = d->n_nodes; c->n_refs = d->n_refs; c->n_tris = d->n_tris; c->n_mats = d->n_mats; c->n_tex = d->n_textures;
 	c->width = d->width; c->height = d->height; c->rank = d->tile_rank; c->nranks = d->tile_nranks;
@@ -850,8 +911,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	{
 		// k_shade's sort key per triangle (shade.hpp: material_class).  Off unless ADYPT_SHADE_BIN=1: measured +10 % k_shade time on both
 		// bench scenes (profiles/r3_ablations_k_trace.txt item 9) — the kernel waits on its gathers, not on divergent vector-ALU work
-		const char *ov = getenv("ADYPT_SHADE_BIN");
-		if(ov && atoi(ov) != 0)
+		if(c->tun.shade_bin)
 		{
 			std::vector<uint8_t> cls((size_t)std::max<int64_t>(d->n_tris, 1), (uint8_t)5);
 			const uint8_t *tri = (const uint8_t *)d->triangles, *mat = (const uint8_t *)d->materials;
@@ -900,6 +960,22 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		TRY_CREATE(upload(c, &c->d_materials, mats.data(), mats.size()));
 	}
 	TRY_CREATE(upload(c, &c->d_local_blocks, c->local_blocks.data(), c->local_blocks.size()));
+	{
+		// k_path looks a hit's triangle up by reference index in a second copy of the records (path.hpp): made here, once, so that nothing is
+		// allocated while frames are traced.  Above the size threshold, or when the memory cannot be had, k_path applies the 4-byte
+		// uTriIndices remap (traversal.glsl:253-254) in its shading round instead — same image.
+		const size_t n16 = (size_t)c->n_refs * kTriFloat4, bytes = std::max<size_t>(n16, 1) * sizeof(float4);
+		const long max_mb = c->tun.ref_triangles_max_mb >= 0 ? c->tun.ref_triangles_max_mb : kRefTrianglesAutoMaxMB;
+		if((bytes >> 20) <= (size_t)max_mb)
+		{
+			if(hipMalloc(&c->d_ref_triangles, bytes) != hipSuccess) { c->d_ref_triangles = nullptr; (void)hipGetLastError(); }
+			else if(n16)
+			{
+				hipLaunchKernelGGL(k_expand_references, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, (const float4 *)c->d_triangles, (const int32_t *)c->d_tri_indices, (size_t)c->n_refs, (float4 *)c->d_ref_triangles);
+				HIP_CREATE(hipGetLastError());
+			}
+		}
+	}
 
 	const size_t npx = (size_t)std::max(c->n_local_px, 64);
 	HIP_CREATE(hipMalloc((void **)&c->d_accum, npx * sizeof(float4)));
@@ -913,7 +989,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		// 1080p image, 128 frames = the maximum for the 260 k-pixel tile shard of an 8-GPU run): the drain of a persistent
 		// launch (its longest rays) is amortised over more work; ADYPT_FRAMES_IN_FLIGHT overrides
 		int fif = (int)std::min<size_t>(kMaxFramesInFlight, std::max<size_t>(1, ((size_t)64 << 20) / npx));
-		if(const char *ov = getenv("ADYPT_FRAMES_IN_FLIGHT")) fif = std::max(1, std::min(kMaxFramesInFlight, atoi(ov)));
+		if(c->tun.frames_in_flight > 0) fif = std::min(kMaxFramesInFlight, c->tun.frames_in_flight);
 		TRY_CREATE(alloc_queues(c, fif));
 	}
 	HIP_CREATE(hipMalloc((void **)&c->d_sobol, (size_t)kMaxFramesInFlight * 64 * sizeof(float)));
@@ -1237,14 +1313,23 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		const bool fused_first = as_batch && use_cache && !c->sun_visibility && c->first_fused;
 		// the counters of all pipes are contiguous: one clearing launch, on the context's stream, before the chains fork
 		clear_counters(c, c->d_counters, n_pipes, c->stream);
+		// a launch or HIP call that fails between the fork and the join must not leave the other chains running unjoined: what follows on the
+		// context's stream (or the caller's next call) only synchronises c->stream, and those chains would still be writing queues, done[] and
+		// counters.  Every early return from here to the join goes through abandon().
+		auto abandon = [&](int code) { for(int k = 1; k < kMaxPipes; ++k) (void)hipStreamSynchronize(c->pipes[k].stream); return code; };
+#define HIP_TRY_JOINED(expr)                                                                          \
+		do {                                                                                           \
+			hipError_t e_ = (expr);                                                                    \
+			if(e_ != hipSuccess) {                                                                     \
+				c->error = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+				return abandon(e_ == hipErrorOutOfMemory ? ADYPT_E_OOM : ADYPT_E_HIP);                 \
+			}                                                                                          \
+		} while(0)
 		if(n_pipes > 1)
 		{
-			HIP_TRY(c, hipEventRecord(c->fork_ev, c->stream));
-			for(int k = 1; k < n_pipes; ++k) HIP_TRY(c, hipStreamWaitEvent(c->pipes[k].stream, c->fork_ev, 0));
+			HIP_TRY_JOINED(hipEventRecord(c->fork_ev, c->stream));
+			for(int k = 1; k < n_pipes; ++k) HIP_TRY_JOINED(hipStreamWaitEvent(c->pipes[k].stream, c->fork_ev, 0));
 		}
-		// a launch that fails in the middle of the chains must not leave the other chains running unjoined: what follows on the context's stream
-		// (or the caller's next call) only synchronises c->stream, and those chains would still be writing queues, done[] and counters
-		auto abandon = [&](int code) { for(int k = 1; k < kMaxPipes; ++k) (void)hipStreamSynchronize(c->pipes[k].stream); return code; };
 		struct Sub { QueueWindow win; FrameArgs f; int grid; };
 		Sub sub[kMaxPipes];
 		for(int k = 0, frame0 = 0; k < n_pipes; ++k)
@@ -1280,17 +1365,10 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		if(fused_bounces && max_bounce > 1)
 		{
 			const Pipe &pipe = c->pipes[0];
-			if(!c->d_ref_triangles) // once per context: the triangle records in reference order (path.hpp)
-			{
-				const size_t n16 = (size_t)c->n_refs * kTriFloat4;
-				HIP_TRY(c, hipMalloc(&c->d_ref_triangles, std::max<size_t>(n16, 1) * sizeof(float4)));
-				if(n16) hipLaunchKernelGGL(k_expand_references, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, (const float4 *)c->d_triangles, (const int32_t *)c->d_tri_indices, (size_t)c->n_refs, (float4 *)c->d_ref_triangles);
-				HIP_TRY(c, hipGetLastError());
-			}
-			SceneArgs sc_ref = sc;
-			sc_ref.triangles = (const float4 *)c->d_ref_triangles;
+			SceneArgs sc_ref = sc; // the triangle records by REFERENCE index when the context holds that copy, else the uTriIndices remap inside k_path
+			if(c->d_ref_triangles) sc_ref.triangles = (const float4 *)c->d_ref_triangles;
 			int r = launch_path(c, pipe, sub[0].win, 1, pipe.counters->count[1], pipe.counters->cursor[1], sub[0].f, sc_ref, px, 1, stats);
-			if(r != ADYPT_OK) return r;
+			if(r != ADYPT_OK) return abandon(r);
 		}
 		for(int b = fused_first ? 1 : 0; b < max_bounce && !fused_bounces; ++b)
 		{
@@ -1328,10 +1406,11 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		}
 		for(int k = 1; k < n_pipes; ++k)
 		{
-			HIP_TRY(c, hipEventRecord(c->pipes[k].done, c->pipes[k].stream));
-			HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pipes[k].done, 0));
+			HIP_TRY_JOINED(hipEventRecord(c->pipes[k].done, c->pipes[k].stream));
+			HIP_TRY_JOINED(hipStreamWaitEvent(c->stream, c->pipes[k].done, 0));
 		}
-		HIP_TRY(c, hipGetLastError());
+		HIP_TRY_JOINED(hipGetLastError());
+#undef HIP_TRY_JOINED
 		if(as_batch)
 		{
 			c->batch_spp = c->spp; c->batch_frames = m; c->cache_group = 0;

@@ -261,6 +261,9 @@ def main() -> None:
     ap.add_argument("--no-single-frame", action="store_true")
     ap.add_argument("--no-extra-blocks", action="store_true", help="skip primary_only and tmp_lifetime_1")
     ap.add_argument("--cache", default=os.environ.get("ADYPT_CACHE", os.path.join(ROOT, ".adypt_cache")))
+    ap.add_argument("--selfcheck", action="store_true", help="N > 1: before anything is timed, render 2 frames on the N GPUs and on GPU 0 alone and compare the two images bit for bit; exit 3 on a mismatch")
+    ap.add_argument("--rehearsal", action="store_true", help="NOT a measurement: enables the library's test hooks (adypt_enable_test_hooks) so that ADYPT_MULTI_SHARED_DEVICE / "
+                                                             "ADYPT_COMM_TRANSPORT=host can stand in for N GPUs on a box with one")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.repeats < 1:
         raise SystemExit("bench.py: --gpus, --steps, --repeats must be >= 1 and --warmup >= 0")
@@ -294,6 +297,8 @@ def main() -> None:
         init_torch()
 
     from adypt_amd import api, distributed as D, scenes, _native as N
+    if args.rehearsal:
+        api.enable_test_hooks()  # without this call the library ignores the hook variables, whatever the environment says
 
     # ---- scene: every rank generates + builds its own copy (0.8 s; nothing to wait for, no shared cache to race on) ------------
     pt_cfg = dict(PT_CFG, tmpLifetime=args.tmp_lifetime)
@@ -301,7 +306,8 @@ def main() -> None:
     t_setup = time.time()
     spec = scenes.make_scene(args.scene, cache, width=args.width, height=args.height, pt=pt_cfg)
     inst = api.Instance()
-    shared_hook = multi and os.environ.get("ADYPT_MULTI_SHARED_DEVICE", "0") not in ("", "0")  # TEST HOOK: N tile shards on ONE device (not a measurement)
+    shared_hook = multi and args.rehearsal and os.environ.get("ADYPT_MULTI_SHARED_DEVICE", "0") not in ("", "0")  # TEST HOOK: N tile shards on ONE device (not a measurement)
+    host_hook = world > 1 and args.rehearsal and os.environ.get("ADYPT_COMM_TRANSPORT") == "host"                 # TEST HOOK: the RCCL call table served through shared memory
     try:
         if multi:
             ok = inst.InitializeFromFile(spec.config_path, shift_seed=SEED, devices=[0] * n_gpus if shared_hook else list(range(n_gpus)))
@@ -385,6 +391,38 @@ def main() -> None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return pt.CommAllReduce([x], "max")[0] if world > 1 else x
+
+    # ---- --selfcheck: the assembled N-GPU image against the 1-GPU image of the same frames, before anything is timed ------------
+    selfcheck = None
+    if args.selfcheck and (multi or world > 1):
+        pt.Reset()
+        pt.Trace(True, 2)
+        img_n = gather()
+        if multi:
+            img_n = pt.ReadResult()
+        elif use_torch:
+            img_n = img_n.cpu().numpy() if (img_n is not None and on_device) else img_n
+        else:
+            img_n = pt.CommReadResult()
+        bad = 0.0
+        if rank == 0:
+            solo = api.HipPathTracer()  # the whole image on this rank's device alone
+            solo.Initialize(inst.m_config.pt_params(SEED), inst.m_hipscene, c.width, c.height, 0 if multi else dev, 0, 1)
+            ip, iv = inst.m_camera.matrices()
+            solo.SetCamera(ip, iv, inst.m_camera.position)
+            solo.Trace(True, 2)
+            img_1 = solo.ReadResult()
+            solo.destroy()
+            differ = int((np.asarray(img_n).reshape(-1).view(np.uint32) != np.asarray(img_1).reshape(-1).view(np.uint32)).sum())
+            selfcheck = {"frames": 2, "words_differing": differ, "image_mean": float(np.asarray(img_1).mean())}
+            bad = 1.0 if differ else 0.0
+            if differ:
+                sys.stderr.write("bench.py --selfcheck: the image assembled from %d GPUs differs from the 1-GPU image in %d of %d words\n" % (n_gpus, differ, img_1.size))
+        if world > 1:
+            bad = reduce_max(bad)  # every rank leaves together
+        if bad:
+            raise SystemExit(3)
+        pt.Reset()
 
     # ---- the timed region, R times from the same start frame: W untimed warm-up steps, then exactly K steps + the one gather ------------
     pt.SetInstrumentation(timing=True, counters=False)
@@ -534,7 +572,7 @@ def main() -> None:
             comm = ("TEST HOOK ADYPT_MULTI_SHARED_DEVICE: %d tile shards on ONE device, device copies instead of RCCL — not a measurement" % n_gpus) if shared_hook \
                 else "native RCCL, ncclCommInitAll, %d ranks in one process" % comm_ranks
         elif world > 1:
-            comm = "torch.distributed" if use_torch else ("host-staged TEST transport (ADYPT_COMM_TRANSPORT=host: not a measurement)" if os.environ.get("ADYPT_COMM_TRANSPORT") == "host"
+            comm = "torch.distributed" if use_torch else ("host-staged TEST transport (ADYPT_COMM_TRANSPORT=host: not a measurement)" if host_hook
                                                          else "native RCCL, ncclCommInitRank, %d ranks, one process per GPU" % comm_ranks)
         else:
             comm = "none"
@@ -550,7 +588,9 @@ def main() -> None:
                           "frames_in_flight": fif, "rays_warmup": rays_warmup, "comm": comm, "comm_ranks": comm_ranks,
                           "devices": ("one process, devices %s" % ([0] * n_gpus if shared_hook else list(range(n_gpus)))) if multi else ("one process per device" if world > 1 else "device %d" % dev),
                           "bounces_in_one_launch": bool(st.get("path_launches", 0) > 0), "timing": "median of %d repeats of [reset, %d warm-up steps, barrier, %d timed steps + gather, barrier]" % (args.repeats, args.warmup, args.steps),
-                          "setup_s": round(t_setup, 2)},
+                          "setup_s": round(t_setup, 2),
+                          "setup_s_per_device": [round(pt.SetupSeconds(i), 2) for i in range(n_gpus)] if multi else None,
+                          "selfcheck": selfcheck, "rehearsal": bool(args.rehearsal)},
                "roofline": roofline, "roofline_hbm_resident": hbm, "cpu_baseline": cpu, "primary_only": primary_only, "tmp_lifetime_1": life1, "single_frame": single,
                "gather_ms": round(gather_ms, 3), "other_kernels_ms": round(st["shade_ms"], 2), "trace_kernels_ms": round(st["trace_ms"], 2),
                "per_rank": None if per_rank is None else {

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ADYPT_ABI_VERSION 3
+#define ADYPT_ABI_VERSION 4
 
 enum adypt_status {
 	ADYPT_OK = 0,
@@ -104,6 +104,15 @@ typedef struct adypt_stats {
 
 int adypt_abi_version(void);
 
+/* TEST-ONLY.  The library has a few hooks that exist so that the multi-GPU paths can be exercised on a machine with ONE GPU (several tile shards
+ * on one device, the RCCL call table served by a shared-memory transport) and so that its own detectors can be tested (a planted queue corruption,
+ * a stalled gather).  They are selected through the environment (csrc/device/tunables.hpp lists them) but are IGNORED unless this function has been
+ * called in the process with ADYPT_TEST_HOOKS_MAGIC: the environment alone cannot change what the shipped library does.  tests/ call it;
+ * bench.py only under --rehearsal.  Returns ADYPT_E_INVALID for any other value.  There is no way to switch the hooks off again. */
+#define ADYPT_TEST_HOOKS_MAGIC 0x7465737468303031ull /* "testh001" */
+int adypt_enable_test_hooks(uint64_t magic);
+int adypt_test_hooks_enabled(void);
+
 /* OglScene::Initialize + OglPathTracer::Initialize (create_buffers / bind_buffers).  Fails with ADYPT_E_NO_DEVICE
  * when no GPU is present. */
 int adypt_create(adypt_ctx **out, const adypt_scene_desc *desc);
@@ -163,8 +172,12 @@ int adypt_get_pipeline(const adypt_ctx *ctx);
 int adypt_set_lookahead(adypt_ctx *ctx, int enabled);
 /* Bounces 1 .. maxBounce-1 of a batch of frames in ONE persistent launch (k_path: the reference's for(b < uMaxBounce) inside one
  * dispatch, shaders/pathtracer.glsl:107, src/Tracer/OglPathTracer.cpp:60) instead of a traversal and a shade launch per bounce.  On by
- * default (ADYPT_FUSED_BOUNCES=0 in the environment: off); used for batches of more than one frame without the sun-visibility query, the
- * sub-batch pipeline or more than 2^26 paths.  Images are bit-identical either way.  The getter says whether the LAST batch used it. */
+ * default (ADYPT_FUSED_BOUNCES=0 in the environment: off); used for every batch — a single frame included (a batch of one; ADYPT_SINGLE_FUSED=0
+ * keeps the launch-per-bounce frame) — unless the sun-visibility query or the sub-batch pipeline is on or the batch has more than 2^26 paths.
+ * Images are bit-identical either way.  The getter says whether the LAST batch used it.
+ * Memory: k_path looks a hit's triangle up by REFERENCE index in a second copy of the 128-byte triangle records (n_refs x 128 B: 43 MB for the
+ * 249 k-triangle bench scene), allocated at adypt_create while it stays below a size threshold (ADYPT_REF_TRIANGLES_MAX_MB; default: while BVH +
+ * copy fit the 256 MB Infinity Cache); above it, or when the allocation fails, k_path goes through the 4-byte uTriIndices remap instead. */
 int adypt_set_fused_bounces(adypt_ctx *ctx, int enabled);
 int adypt_get_fused_bounces(const adypt_ctx *ctx);
 int adypt_get_lookahead_frames(const adypt_ctx *ctx); /* frames currently parked */
@@ -231,14 +244,16 @@ int adypt_untile_host(int width, int height, int rank, int nranks, const float *
  * (1) One process, N devices — what a C++ host such as the reference's Instance (src/Instance.cpp:33-57) needs to use more
  * than one GPU: one adypt_multi stands for N contexts (tile rank i on device_ids[i], scene replicated), every call fans out
  * to all of them from the calling thread (the per-device work is asynchronous), adypt_multi_read_radiance gathers.
- * Test hook for single-GPU machines: with ADYPT_MULTI_SHARED_DEVICE=1 in the environment a device may be listed several times
- * (RCCL refuses that); the shards then share the device and the peer -> root transfers are device-to-device copies. */
+ * Test hook for single-GPU machines (only after adypt_enable_test_hooks): with ADYPT_MULTI_SHARED_DEVICE=1 in the environment a device may be
+ * listed several times (RCCL refuses that); the shards then share the device and the peer -> root transfers are device-to-device copies. */
 typedef struct adypt_multi adypt_multi;
 int adypt_create_multi(adypt_multi **out, const adypt_scene_desc *desc /* device, tile_rank, tile_nranks ignored */,
                        const int *device_ids, int n_dev);
 void adypt_destroy_multi(adypt_multi *m);
 const char *adypt_multi_last_error(const adypt_multi *m); /* m may be NULL: error of the last failed adypt_create_multi */
 int adypt_multi_device_count(const adypt_multi *m);
+/* seconds adypt_create took for device_ids[i] (the N contexts are created concurrently, one host thread each); -1 for a bad index */
+double adypt_multi_setup_seconds(const adypt_multi *m, int i);
 adypt_ctx *adypt_multi_context(adypt_multi *m, int i);    /* the context of device_ids[i] (statistics, tunables); owned by m */
 int adypt_multi_set_params(adypt_multi *m, const adypt_pt_params *params);
 int adypt_multi_set_camera(adypt_multi *m, const float origin[3], const float inv_proj[16], const float inv_view[16]);
@@ -258,6 +273,9 @@ int adypt_multi_get_spp(const adypt_multi *m);
 int adypt_multi_read_radiance(adypt_multi *m, float *rgb);
 /* the same, leaving the assembled W*H*3 fp32 image in the HBM of device_ids[0] (library-owned buffer, valid until the next
  * gather or adypt_destroy_multi) — resident like the reference's result texture */
+/* Bounded: if the gather (this call and adypt_comm_gather_radiance alike) has not finished within ADYPT_GATHER_TIMEOUT seconds (environment;
+ * default 120, 0 = unbounded) a watchdog thread prints where it stands and the state of every rank's stream to stderr and ENDS THE PROCESS with
+ * exit code 86 — a collective whose peer never arrives cannot be cancelled, and a process that has touched the GPU must not be re-executed. */
 int adypt_multi_gather_radiance(adypt_multi *m, void **rgb_device);
 /* creates the RCCL communicators now (otherwise: at the first gather, and only when n_dev > 1); lets a caller — and the
  * one-GPU test — find out at start-up whether RCCL is usable */

@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version_and_struct_sizes():
     from adypt_amd import _native as N
-    assert N.lib.adypt_abi_version() == 3
+    assert N.lib.adypt_abi_version() == 4
     assert ctypes.sizeof(N.Hit) == 36 and ctypes.sizeof(N.PtParams) == 40 and ctypes.sizeof(N.BvhParams) == 12
 
 

@@ -344,7 +344,7 @@ def test_cli_progressive_and_multi_device(scene_cache, tmp_path):
     assert inst.InitializeFromFile(spec.config_path, shift_seed=5)
     inst.m_path_tracer.Trace(True, 7)
     want, shown = inst.m_path_tracer.ReadResult(), inst.m_path_tracer.ReadDisplay()
-    for tag, extra, env in (("one", ["--device", "0"], {}), ("three", ["--devices", "0,0,0"], {"ADYPT_MULTI_SHARED_DEVICE": "1"})):
+    for tag, extra, env in (("one", ["--device", "0"], {}), ("three", ["--devices", "0,0,0", "--test-hooks"], {"ADYPT_MULTI_SHARED_DEVICE": "1"})):
         out, png = str(tmp_path / (tag + ".exr")), str(tmp_path / (tag + ".png"))
         r = subprocess.run([exe, spec.config_path, "--spp", "7", "--save-every", "3", "--out", out, "--preview", png, "--seed", "5"] + extra,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **env))

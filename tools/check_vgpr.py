@@ -7,17 +7,17 @@ slot; DESIGN.md, the append_slot fault) was only ever seen in a build whose k_ge
 claims under the slot-claim audit without one error.  Which kernels contain append_slot is read from the assembly, not from a list of names: its
 signature is the pair of workgroup barriers followed by v_mbcnt_hi with a returning global atomic between them (k_path uses LDS lists and
 is not matched).  python tools/check_vgpr.py"""
-import os, re, subprocess, sys, tempfile
+import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "adypt_amd", "csrc")
-FLAGS = "-std=c++17 -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -munsafe-fp-atomics -fno-slp-vectorize -mllvm -disable-machine-licm -DADYPT_BUILD --cuda-device-only -S".split()
 MIN_VGPRS = 17
 
 
 def kernels(src):
-    with tempfile.NamedTemporaryFile(suffix=".s") as t:
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + [os.path.join(CSRC, src), "-o", t.name], stderr=subprocess.DEVNULL)
-        text = open(t.name).read()
+    """The assembly comes from the Makefile's own `asm` target — the compiler, architecture and flags of the shipped objects (ROCM / HIPCC / ARCH
+    overrides included), not a copy of the flag list kept here."""
+    subprocess.check_call(["make", "-s", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL)
+    text = open(os.path.join(CSRC, "build", os.path.basename(src).replace(".hip", ".s"))).read()
     counts = dict((n, int(v)) for n, v in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text))
     out = []
     for name, n in counts.items():

@@ -29,6 +29,7 @@ def rank_main(scene, w, h, spp):
     from adypt_amd import api, distributed as D, scenes
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     spec = scenes.make_scene(scene, os.environ["ADYPT_CACHE"], width=w, height=h, pt={"maxBounce": 5, "tmpLifetime": 4, "subpixel": 3})
+    api.enable_test_hooks()  # the host-staged transport is a test hook: ignored by the library unless asked for explicitly
     inst = api.Instance()
     assert inst.InitializeFromFile(spec.config_path, shift_seed=4711, device=0, tile_rank=rank, tile_nranks=world)
     pt = inst.m_path_tracer
