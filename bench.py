@@ -589,7 +589,7 @@ def main() -> None:
                           "devices": ("one process, devices %s" % ([0] * n_gpus if shared_hook else list(range(n_gpus)))) if multi else ("one process per device" if world > 1 else "device %d" % dev),
                           "bounces_in_one_launch": bool(st.get("path_launches", 0) > 0), "timing": "median of %d repeats of [reset, %d warm-up steps, barrier, %d timed steps + gather, barrier]" % (args.repeats, args.warmup, args.steps),
                           "setup_s": round(t_setup, 2),
-                          "setup_s_per_device": [round(pt.SetupSeconds(i), 2) for i in range(n_gpus)] if multi else None,
+                          "setup_s_per_device": [round(pt.SetupSeconds(i), 3) for i in range(n_gpus)] if multi else None,
                           "selfcheck": selfcheck, "rehearsal": bool(args.rehearsal)},
                "roofline": roofline, "roofline_hbm_resident": hbm, "cpu_baseline": cpu, "primary_only": primary_only, "tmp_lifetime_1": life1, "single_frame": single,
                "gather_ms": round(gather_ms, 3), "other_kernels_ms": round(st["shade_ms"], 2), "trace_kernels_ms": round(st["trace_ms"], 2),

@@ -51,7 +51,7 @@ def test_single_process_multi_device_path_on_one_card(tmp_path):
     assert len(pr["rays"]) == 3 and sum(pr["rays"]) == a["config"]["rays_per_step"] * 4 and all(r > 0 for r in pr["rays"])
     assert b["repeats"] == 2 and len(b["ms_per_step_all"]) == 2 and b["value_min"] <= b["value"] <= b["value_max"]
     assert b["config"]["selfcheck"] == {"frames": 2, "words_differing": 0, "image_mean": b["config"]["selfcheck"]["image_mean"]} and b["config"]["rehearsal"] is True
-    assert len(b["config"]["setup_s_per_device"]) == 3 and all(t > 0 for t in b["config"]["setup_s_per_device"])
+    assert len(b["config"]["setup_s_per_device"]) == 3 and all(t >= 0 for t in b["config"]["setup_s_per_device"]) and b["config"]["setup_s_per_device"][0] > 0
     # without the hook the same command must refuse: the box has one device
     real = _bench(["--gpus", "3", "--steps", "4", "--warmup", "2", "--cache", str(tmp_path)] + SMALL)
     assert real.returncode != 0 and not real.stdout.strip()
