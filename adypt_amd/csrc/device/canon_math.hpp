@@ -29,6 +29,24 @@ typedef float V2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
 __device__ __forceinline__ V2 v2s(float s) { V2 r; r.x = s; r.y = s; return r; }
 __device__ __forceinline__ V2 pk_fma(V2 a, V2 b, V2 c) { return __builtin_elementwise_fma(a, b, c); }
+// fma(a, s, c) per half with s = the HIGH half of the register pair `b` (a loaded float4's .y or .w): v_pk_fma_f32 reads it in place through op_sel.
+// Written out because the compiler forms this broadcast with a v_mov_b32 into a fresh pair (3 per Woop test).  Same IEEE fma per half as pk_fma.
+__device__ __forceinline__ V2 pk_fma_hi(V2 a, V2 b, V2 c)
+{
+	V2 r;
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+// (x byte J) << (s byte J) for two words of four packed bytes, one SDWA instruction (the shift uses the low 5 bits of the selected byte)
+template <int J> __device__ __forceinline__ uint32_t shl_bytes(uint32_t s, uint32_t x)
+{
+	uint32_t r;
+	if(J == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(r) : "v"(s), "v"(x));
+	else if(J == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(r) : "v"(s), "v"(x));
+	else if(J == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(r) : "v"(s), "v"(x));
+	else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(r) : "v"(s), "v"(x));
+	return r;
+}
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 __device__ __forceinline__ F3 cross3(F3 a, F3 b)
 {

@@ -220,12 +220,24 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		od_x = v2(ox, dir.x); od_y = v2(oy, dir.y); od_z = v2(oz, dir.z);
 	};
 
+	// the two base pointers of the trip's loads, held in SGPRs for the whole loop (as plain kernel arguments the compiler re-loads them from the
+	// kernarg segment inside the trip: a scalar load and its wait in front of every node / triangle fetch)
+	const float4 *trip_woop = a.woop;
+	const uint4 *trip_nodes = a.nodes;
+	asm volatile("" : "+s"(trip_woop), "+s"(trip_nodes));
+
+	// Shape of the loop: NO `continue`.  Every iteration runs top to bottom — start rays, exchange, trip — and a wave-uniform flag skips the
+	// trip when the exchange handed out rays (they are started first) or the wave holds none.  With `continue` edges around the trip the
+	// loop-carried ray state lived in two register sets, one for the blocks in front of the trip and one for the trip, with 10 copies at the
+	// loop's latch and more at the trip's head: ~17 of a trip's ~340 vector instructions (profiles/r5_trip_budget.json).
+	bool any_setup = __ballot(setup) != 0ull; // wave-uniform: some lane is about to start a ray (kept instead of a vote per iteration)
 	for(;;)
 	{
 		// ---------------- start the rays of the slots the lanes have just taken (traversal.glsl:16-35) ----------------
-		const unsigned long long starting = __ballot(setup);
-		if(starting)
+		if(any_setup)
 		{
+			const unsigned long long starting = __ballot(setup);
+			any_setup = false;
 			asm volatile("; ADYPT_MARK setup_begin"); // (comments in the assembly: tools/instruction_mix.py weights the blocks of the loop by how often they run)
 			if(setup)
 			{
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		}
 
 		// ---------------- exchange with the workgroup: deposit finished rays, shade a batch, take ready rays ----------------
+		bool skip_trip = false; // wave-uniform
 		const unsigned long long idle = __ballot(!active);
 		const uint32_t n_idle = (uint32_t)__popcll(idle);
 		if(n_idle >= a.refill_min)
@@ -431,19 +444,23 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				}
 				asm volatile("; ADYPT_MARK exchange_end");
 				__builtin_amdgcn_s_setprio(0);
-				if(__ballot(setup)) continue;
+				any_setup = __ballot(setup) != 0ull;
+				skip_trip = any_setup; // the rays just taken are started first
 			}
 		}
-		const unsigned long long live = __ballot(active);
-		if(STATS && lane == 0) { wp[0] += 1; wp[1] += (unsigned long long)__popcll(live); }
-		if(live == 0ull)
+		const unsigned long long live = ~idle; // (every lane of the wave runs this loop; `active` has not changed since the vote above)
+		if(!skip_trip)
 		{
-			if(STATS && lane == 0) wp[7] += 1;
-			if(uni(__hip_atomic_load(&ctl->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break; // the global queue is dry and the workgroup's last path has ended
-			__builtin_amdgcn_s_sleep(8);
-			continue;
+			if(STATS && lane == 0) { wp[0] += 1; wp[1] += (unsigned long long)__popcll(live); }
+			if(live == 0ull)
+			{
+				if(STATS && lane == 0) wp[7] += 1;
+				if(uni(__hip_atomic_load(&ctl->live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) break; // the global queue is dry and the workgroup's last path has ended
+				__builtin_amdgcn_s_sleep(8);
+				skip_trip = true;
+			}
 		}
-
+		if(!skip_trip)
 #include "traverse_trip.inc"
 	}
 

@@ -193,6 +193,8 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 		if(lane == (int)__builtin_ctzll(m)) { wp[slot] += 1; wp[slot + 1] += (unsigned long long)__popcll(m); }
 	};
 
+	const float4 *const trip_woop = a.woop; // (the trip's two base pointers: traverse_trip.inc)
+	const uint4 *const trip_nodes = a.nodes;
 	for(;;)
 	{
 		// ---------------- refill idle lanes ----------------
@@ -356,13 +358,13 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 		}
 		const unsigned long long live = __ballot(active);
 		if(STATS && lane == 0) { wp[0] += 1; wp[1] += (unsigned long long)__popcll(live); }
+		// (no `continue` around the trip: with one, the loop-carried ray state lives in two register sets and is copied at the loop's latch — path.hpp)
 		if(live == 0ull)
 		{
 			if(STATS && lane == 0) wp[7] += 1;
 			if(exhausted && loc_next == loc_end) break;
-			continue;
 		}
-
+		else
 #include "traverse_trip.inc"
 	}
 
