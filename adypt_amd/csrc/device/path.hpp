@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		dir.y = fabsf(dir.y) > ooeps ? dir.y : (dir.y >= 0 ? ooeps : -ooeps);
 		dir.z = fabsf(dir.z) > ooeps ? dir.z : (dir.z >= 0 ? ooeps : -ooeps);
 		dir = normalize3(dir);
-		idir = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+		idir = f3(rcp_ieee(dir.x), rcp_ieee(dir.y), rcp_ieee(dir.z));
 		nx = dir.x < 0; ny = dir.y < 0; nz = dir.z < 0;
 		octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
 		od_x = v2(ox, dir.x); od_y = v2(oy, dir.y); od_z = v2(oz, dir.z);

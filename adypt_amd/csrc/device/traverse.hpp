@@ -338,7 +338,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 				dir.y = fabsf(dir.y) > ooeps ? dir.y : (dir.y >= 0 ? ooeps : -ooeps);
 				dir.z = fabsf(dir.z) > ooeps ? dir.z : (dir.z >= 0 ? ooeps : -ooeps);
 				dir = normalize3(dir);
-				idir = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+				idir = f3(rcp_ieee(dir.x), rcp_ieee(dir.y), rcp_ieee(dir.z));
 				nx = dir.x < 0; ny = dir.y < 0; nz = dir.z < 0;
 				octinv = 7u - ((nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u));
 				F3 origin = f3(ro.x, ro.y, ro.z);

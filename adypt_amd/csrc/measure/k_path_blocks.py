@@ -1,0 +1,82 @@
+"""Measurement variant of k_path (NOT product code): every block of the persistent loop that the hardware may skip — the blocks behind a wave-level
+branch — is bracketed by `; ADYPT_MARK <name>_begin / _end` comments in the assembly and counts, in an SGPR, how often a wave ENTERS it (an s_add in the
+block itself: it runs exactly when the block's vector instructions are issued, whatever the lanes' masks).  tools/trip_budget.py reads the static
+instruction counts between the marks (no GPU needed); tools/path_block_counts.py reads the entry counts on the GPU box; together they are the EXECUTED
+vector instructions per trip (profiles/r5_trip_budget.json, r5_k_path_block_counts.json), which tools/valu_issue_model.py checks against SQ_INSTS_VALU.
+    tools/build_variant.sh blocks --transform adypt_amd/csrc/measure/k_path_blocks.py
+Blocks: loop (every iteration) | setup | exchange | shade | trip, and inside the trip: A_pop (A_pop_lds / A_pop_spill) A_choose A_push (A_push_lds is the
+block's remainder / A_push_spill) B_tri_load B_node_load C_woop D_slab E_flush.  What of the trip lies outside every block runs with every trip."""
+import sys
+d = sys.argv[1]
+import os
+COUNT = os.environ.get("ADYPT_BLOCKS_COUNT", "0") != "0"   # 0: marks only (static counts: tools/trip_budget.py); 1: marks + entry counters (tools/path_block_counts.py)
+NAMES = ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_push", "B_tri_load", "B_node_load", "C_woop", "D_slab", "E_flush"]
+# Counters: a value that is modified inside a divergent block cannot live in an SGPR the compiler allocates (the merge after the block is per lane).
+# So k_path is held to 96 SGPRs (amdgpu_num_sgpr) and the counters live in s96 .. s101, touched only by inline assembly: two 16-bit counters per
+# register (a wave makes < 65536 trips per launch at the batch sizes measured).
+
+
+def edit(name, pairs):
+    p = d + "/" + name
+    s = open(p).read()
+    for old, new in pairs:
+        assert s.count(old) == 1, (name, s.count(old), old[:70])
+        s = s.replace(old, new)
+    open(p, "w").write(s)
+
+
+def enter(n):  # the counter of block n goes up once per wave that enters the block (SALU: not a vector instruction, blind to the exec mask)
+    # (sched_barrier: without it the scheduler is free to move a block's arithmetic across the comment, and both marks end up at the block's top)
+    if n not in NAMES or not COUNT:
+        return '__builtin_amdgcn_sched_barrier(0); asm volatile("; ADYPT_MARK %s_begin"); __builtin_amdgcn_sched_barrier(0);' % n
+    i = NAMES.index(n)
+    return '__builtin_amdgcn_sched_barrier(0); asm volatile("s_add_u32 s%d, s%d, %s ; ADYPT_MARK %s_begin" ::: "s%d"); __builtin_amdgcn_sched_barrier(0);' % (96 + i // 2, 96 + i // 2, "0x10000" if i & 1 else "1", n, 96 + i // 2)
+
+
+def leave(n):
+    return '__builtin_amdgcn_sched_barrier(0); asm volatile("; ADYPT_MARK %s_end"); __builtin_amdgcn_sched_barrier(0);' % n
+
+
+edit("traverse_trip.inc", [
+    ("			const bool can_pop = !pending && ng_y <= 0x00ffffffu && sp != 0;", "			asm volatile(\"; ADYPT_MARK sec_A\");\n			const bool can_pop = !pending && ng_y <= 0x00ffffffu && sp != 0;"),
+    ("			auto swap1 = [](uint32_t v)", "			asm volatile(\"; ADYPT_MARK sec_B\");\n			auto swap1 = [](uint32_t v)"),
+    ("			float tt, tu, tv;\n", "			asm volatile(\"; ADYPT_MARK sec_C\");\n			float tt, tu, tv;\n"),
+    ("			if(tg_y != 0)\n			{\n				// more triangles of this node", "			asm volatile(\"; ADYPT_MARK sec_D\");\n			if(tg_y != 0)\n			{\n				// more triangles of this node"),
+    ("			if(active && tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))", "			asm volatile(\"; ADYPT_MARK sec_E\");\n			if(active && tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))"),
+    ("			if(can_pop)\n			{\n				--sp;", "			if(can_pop)\n			{\n				" + enter("A_pop") + "\n				--sp;"),
+    ("					const uint2 g = my_spill[(size_t)(sp - a.lds_depth) * total_lanes];\n					ng_x = g.x; ng_y = g.y;\n					asm volatile(\"\" : \"+v\"(ng_x), \"+v\"(ng_y));\n				}\n			}",
+     "					" + enter("A_pop_spill") + "\n					const uint2 g = my_spill[(size_t)(sp - a.lds_depth) * total_lanes];\n					ng_x = g.x; ng_y = g.y;\n					asm volatile(\"\" : \"+v\"(ng_x), \"+v\"(ng_y));\n					" + leave("A_pop_spill") + "\n				}\n				" + leave("A_pop") + "\n			}"),
+    ("			if(choose)\n			{\n				const uint32_t imask = ng_y;", "			if(choose)\n			{\n				" + enter("A_choose") + "\n				const uint32_t imask = ng_y;"),
+    ("				pending = true;\n			}", "				pending = true;\n				" + leave("A_choose") + "\n			}"),
+    ("			if(push_ok)\n			{\n				if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);\n				else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);\n				++sp;",
+     "			if(push_ok)\n			{\n				" + enter("A_push") + "\n				if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);\n				else { " + enter("A_push_spill") + " my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y); " + leave("A_push_spill") + " }\n				++sp;"),
+    ("				if(STATS) depth_after_push = (uint32_t)sp;\n			}", "				if(STATS) depth_after_push = (uint32_t)sp;\n				" + leave("A_push") + "\n			}"),
+    ("			if(do_test)\n			{\n				const float4 *w0 = trip_woop", "			if(do_test)\n			{\n				" + enter("B_tri_load") + "\n				const float4 *w0 = trip_woop"),
+    ("				wp0 = w0[0]; wp1 = w0[1]; wp2 = w0[2];\n			}", "				wp0 = w0[0]; wp1 = w0[1]; wp2 = w0[2];\n				" + leave("B_tri_load") + "\n			}"),
+    ("			if(pending && tg_y == 0)\n			{\n				const uint4 *np = trip_nodes", "			if(pending && tg_y == 0)\n			{\n				" + enter("B_node_load") + "\n				const uint4 *np = trip_nodes"),
+    ("				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];\n			}", "				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];\n				" + leave("B_node_load") + "\n			}"),
+    ("			if(do_test)\n			{\n				if(STATS) wave_event(2);", "			if(do_test)\n			{\n				" + enter("C_woop") + "\n				if(STATS) wave_event(2);"),
+    ("				geom_ok = tt > t_tmin && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f;\n			}", "				geom_ok = tt > t_tmin && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f;\n				" + leave("C_woop") + "\n			}"),
+    ("				pending = false;\n				if(ANY) overflow |= push_overflow;", "				" + enter("D_slab") + "\n				pending = false;\n				if(ANY) overflow |= push_overflow;"),
+    ("				tg_y = hitmask & 0x00ffffffu;\n			}", "				tg_y = hitmask & 0x00ffffffu;\n				" + leave("D_slab") + "\n			}"),
+    ("				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert", "				" + enter("E_flush") + "\n				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert"),
+    ("				active = false;\n			}\n		}", "				active = false;\n				" + leave("E_flush") + "\n			}\n		}"),
+])
+# (k_trace includes the trip too: it gets a dummy counter array)
+zero = " ".join('asm volatile("s_mov_b32 s%d, 0" ::: "s%d");' % (r, r) for r in range(96, 102))
+read = " ".join('asm volatile("s_mov_b32 %%0, s%d" : "=s"(bc[%d]));' % (96 + i, i) for i in range(6))
+pairs = [
+    ('				asm volatile("; ADYPT_MARK exchange_begin");', "				" + enter("exchange")),
+    ('					asm volatile("; ADYPT_MARK shade_begin");', "					" + enter("shade")),
+    ('			asm volatile("; ADYPT_MARK setup_begin");', "			" + enter("setup")),
+    ("		if(!skip_trip)\n#include \"traverse_trip.inc\"", "		if(!skip_trip)\n		{\n		" + enter("trip") + "\n#include \"traverse_trip.inc\"\n		" + leave("trip") + "\n		}"),
+]
+if COUNT:
+    pairs += [
+        ("template <bool STATS>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathKernArgs K)\n{",
+         "template <bool STATS>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) __attribute__((amdgpu_num_sgpr(96))) void k_path(PathKernArgs K)\n{\n	" + zero),
+        ("	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------",
+         "	{ uint32_t bc[6]; " + read + "\n	if(lane == 0) for(int i = 0; i < 6; ++i) atomicAdd(&a.stats->wave_profile[i], (((unsigned long long)(bc[i] >> 16)) << 32) | (unsigned long long)(bc[i] & 0xffffu)); } // (k_path<false> leaves wave_profile alone)\n"
+         "	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------"),
+    ]
+edit("path.hpp", pairs)
