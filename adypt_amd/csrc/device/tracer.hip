@@ -131,6 +131,12 @@ struct adypt_ctx {
 	int pipeline = kDefaultPipes; // sub-batches per batch (adypt_set_pipeline); 1 = one chain on the context's stream
 	Pipe pipes[kMaxPipes];
 	hipEvent_t fork_ev = nullptr;
+	// Single frames in a row (one frame per wavefront pass): frame k's k_path runs on pipe 1 + (k & 1) while frame k + 1's bounce 0 and k_path are already
+	// enqueued behind it on the other pipe, so the END of frame k's launch (its last paths' sequential bounces, ~0.5 ms of 2 ms) is covered by frame k + 1.
+	// roll_frame[s] = the frame whose k_path is in flight (or finished, not yet applied) in slot s, -1 = none
+	int roll_frame[2] = {-1, -1};
+	hipEvent_t roll_ready[2] = {nullptr, nullptr}; // bounce 0 of the slot's frame is done (context's stream) -> its k_path may start (pipe's stream)
+	int single_overlap = 1;        // ADYPT_SINGLE_OVERLAP=0: single frames strictly one after the other
 	float4 *q_o[2] = {nullptr, nullptr}, *q_d[2] = {nullptr, nullptr}, *q_col[2] = {nullptr, nullptr};
 	float4 *d_hit = nullptr;
 	float4 *sh_o = nullptr, *sh_d = nullptr, *sh_col = nullptr, *sh_hit = nullptr; // sun-visibility queue (allocated when enabled)
@@ -295,8 +301,10 @@ inline void end_timing(hipEvent_t *stop, hipStream_t stream) { if(stop) (void)hi
 
 void harvest_events(adypt_ctx *c)
 {
+	std::vector<EventPair> pending; // launches of a frame started ahead on its own stream may still be running: their turn comes later
 	for(EventPair &p : c->events)
 	{
+		if(hipEventQuery(p.b) == hipErrorNotReady) { pending.push_back(p); continue; }
 		float ms = 0.0f;
 		if(hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
 		{
@@ -305,7 +313,7 @@ void harvest_events(adypt_ctx *c)
 		}
 		c->free_events.push_back(p);
 	}
-	c->events.clear();
+	c->events.swap(pending);
 }
 
 void clear_counters(adypt_ctx *c, FrameCounters *first, int n, hipStream_t stream)
@@ -601,7 +609,8 @@ int alloc_queues_raw(adypt_ctx *c, int fif)
 		HIP_TRY(c, hipMalloc((void **)&c->q_col[i], nq * sizeof(float4)));
 	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_hit, nq * sizeof(float4)));
-	HIP_TRY(c, hipMalloc((void **)&c->d_done, paths * sizeof(float4))); // finished samples of a batch / parked radiance of live paths
+	// finished samples of a batch / parked radiance of live paths; two frames at least: single frames in a row alternate between two slots
+	HIP_TRY(c, hipMalloc((void **)&c->d_done, npx * (size_t)std::max(fif, 2) * sizeof(float4)));
 	return ADYPT_OK;
 }
 
@@ -729,7 +738,125 @@ int resolve_batch_frames(adypt_ctx *c, const SceneArgs &sc, const PixelArgs &px,
 
 // frames traced ahead belong to the camera / parameters / queues they were traced with: anything that changes those drops
 // them (they are re-traced on demand — the sample sequence is a function of the frame index alone)
-inline void drop_lookahead(adypt_ctx *c) { c->ahead_count = 0; c->ahead_pos = 0; }
+// The same for single frames whose k_path was started ahead in a rolling slot: waited for (their kernels read queues, counters and the camera's
+// cache image) and forgotten.
+void drop_rolling(adypt_ctx *c)
+{
+	if(c->roll_frame[0] < 0 && c->roll_frame[1] < 0) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for(int s = 0; s < 2; ++s) { (void)hipStreamSynchronize(c->pipes[1 + s].stream); c->roll_frame[s] = -1; }
+}
+inline void drop_lookahead(adypt_ctx *c) { c->ahead_count = 0; c->ahead_pos = 0; drop_rolling(c); }
+
+
+// Sobol::Next (src/Util/Sobol.cpp:16-21) for frames [first, first + m): staged in a pinned slot, copied to `dst` on the context's stream
+int upload_sobol(adypt_ctx *c, int first, int m, float *dst)
+{
+	const int max_bounce = c->params.max_bounce;
+	const int slot = c->sobol_next;
+	c->sobol_next = (slot + 1) % adypt_ctx::kSobolSlots;
+	HIP_TRY(c, hipEventSynchronize(c->sobol_done[slot])); // the copy that last used this slot has left it
+	std::vector<float> pts((size_t)m * 2 * max_bounce);
+	int r = adypt_sobol_points(2 * max_bounce, first, m, pts.data());
+	if(r != ADYPT_OK) return fail(c, r, adypt_host_last_error());
+	float *padded = c->h_sobol[slot];
+	memset(padded, 0, (size_t)m * 64 * sizeof(float));
+	for(int k = 0; k < m; ++k) memcpy(&padded[(size_t)k * 64], &pts[(size_t)k * 2 * max_bounce], sizeof(float) * 2 * (size_t)max_bounce);
+	HIP_TRY(c, hipMemcpyAsync(dst, padded, (size_t)m * 64 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipEventRecord(c->sobol_done[slot], c->stream));
+	return ADYPT_OK;
+}
+
+// the arguments of single frame `frame` in rolling slot `s`: a batch of one whose Sobol points, finished samples, queue window, counters and
+// stream are the slot's
+void roll_frame_args(const adypt_ctx *c, int frame, int s, FrameArgs *f)
+{
+	fill_frame(c, f);
+	f->spp = frame; f->n_frames = 1; f->frame_first = 0; f->frame_stride = 1; f->batched = 1;
+	f->sobol = c->d_sobol + (size_t)s * 64;
+	f->done = c->d_done + (size_t)s * (size_t)std::max(c->n_local_px, 64);
+}
+
+// Enqueues single frame `frame` in rolling slot `s`: [camera rays of a re-tracing frame ->] counters -> k_shade_first on the CONTEXT's stream (it
+// reads the primary-hit cache, which the next re-tracing frame rewrites on that stream), then k_path on the slot's own stream behind an event.
+// Nothing here waits for the slot's previous frame: the caller has enqueued that frame's running-mean step — which waits for its k_path — on the
+// context's stream before it calls this.
+int roll_launch(adypt_ctx *c, const SceneArgs &sc, const PixelArgs &px, bool stats, int frame, int s)
+{
+	const Pipe &pipe = c->pipes[1 + s];
+	const QueueWindow win = pipe_window(c, s, 2);
+	FrameArgs f;
+	roll_frame_args(c, frame, s, &f);
+	int r = upload_sobol(c, frame, 1, c->d_sobol + (size_t)s * 64);
+	if(r != ADYPT_OK) return r;
+	if(frame % std::max(1, c->params.tmp_lifetime) == 0)
+	{
+		// the frame re-traces its primary rays (pathtracer.glsl:113-127): one camera launch into the cache image, on the context's stream
+		FrameArgs fc = f;
+		fc.frame_stride = std::max(1, c->params.tmp_lifetime);
+		r = launch_trace_camera(c, c->pipes[0], full_window(c), fc, px, 1, stats);
+		if(r != ADYPT_OK) return r;
+	}
+	clear_counters(c, pipe.counters, 1, c->stream);
+	hipEvent_t *stop = begin_timing(c, 1, c->stream);
+	QueueArgs q = queue_args(c, win, 0, pipe.counters->count[0], pipe.counters->count[1], 1); // out = queue 1 = bounce 1's rays
+	audit_before(c, q, c->stream, 1 + s);
+	hipLaunchKernelGGL(k_shade_first, dim3((unsigned)(c->n_local_px / kShadeThreads)), dim3(kShadeThreads), 0, c->stream, f, sc, q, px, stats ? 1 : 0);
+	audit_after(c, q, c->stream, 1 + s);
+	end_timing(stop, c->stream);
+	HIP_TRY(c, hipGetLastError());
+	c->last_batch_fused = true;
+	if(c->params.max_bounce > 1)
+	{
+		HIP_TRY(c, hipEventRecord(c->roll_ready[s], c->stream));
+		HIP_TRY(c, hipStreamWaitEvent(pipe.stream, c->roll_ready[s], 0));
+		SceneArgs sc_ref = sc;
+		if(c->d_ref_triangles) sc_ref.triangles = (const float4 *)c->d_ref_triangles;
+		r = launch_path(c, pipe, win, 1, pipe.counters->count[1], pipe.counters->cursor[1], f, sc_ref, px, 1, stats);
+		if(r != ADYPT_OK) return r;
+	}
+	HIP_TRY(c, hipEventRecord(pipe.done, pipe.stream));
+	c->roll_frame[s] = frame;
+	return ADYPT_OK;
+}
+
+// frame c->spp as a rolling single frame; `more` = the call wants the frame after it too
+int trace_rolling_frame(adypt_ctx *c, const SceneArgs &sc, const PixelArgs &px, bool stats, bool more)
+{
+	const int frame = c->spp, s = frame & 1;
+	int r;
+	if(c->roll_frame[s] != frame)
+	{
+		if(c->roll_frame[s] >= 0) drop_rolling(c); // (a slot that holds some other frame: cannot happen while frames come in order)
+		r = roll_launch(c, sc, px, stats, frame, s);
+		if(r != ADYPT_OK) { drop_rolling(c); return r; }
+	}
+	// The frame after it, when this call asks for it (or the caller switched look-ahead on and it belongs to the same tmpLifetime group, so that
+	// image 1 stays what frame-by-frame tracing leaves there): enqueued NOW, behind frame `frame`'s k_path — it fills the compute units as that launch's
+	// workgroups end.  Its slot's previous frame (frame - 1) had its running-mean step enqueued by the previous call of this function.
+	const int life = std::max(1, c->params.tmp_lifetime);
+	const bool ahead = c->single_overlap && (more || (c->lookahead && (frame + 1) % life != 0));
+	if(ahead && c->roll_frame[s ^ 1] != frame + 1)
+	{
+		if(c->roll_frame[s ^ 1] >= 0) drop_rolling(c);
+		if(c->roll_frame[s] != frame) { r = roll_launch(c, sc, px, stats, frame, s); if(r != ADYPT_OK) { drop_rolling(c); return r; } } // (dropped with the other slot)
+		r = roll_launch(c, sc, px, stats, frame + 1, s ^ 1);
+		if(r != ADYPT_OK) { drop_rolling(c); return r; }
+	}
+	// running mean of frame `frame` (pathtracer.glsl:224-226) once its k_path has ended
+	HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pipes[1 + s].done, 0));
+	FrameArgs f;
+	roll_frame_args(c, frame, s, &f);
+	hipEvent_t *stop = begin_timing(c, 1, c->stream);
+	hipLaunchKernelGGL(k_resolve, dim3((c->n_local_px + 255) / 256), dim3(256), 0, c->stream, f, sc, px, 0, 1);
+	end_timing(stop, c->stream);
+	HIP_TRY(c, hipGetLastError());
+	c->roll_frame[s] = -1;
+	c->batch_spp = frame; c->batch_frames = 1; c->cache_group = 0; c->ahead_pos = 1; c->ahead_count = 0;
+	c->spp += 1;
+	return ADYPT_OK;
+}
 
 }  // namespace
 
@@ -754,7 +881,7 @@ Tunables read_tunables()
 	t.frames_in_flight = (int)num("ADYPT_FRAMES_IN_FLIGHT", 1, kMaxFramesInFlight, 0);
 	t.pipeline = (int)num("ADYPT_PIPELINE", 1, kMaxPipes, kDefaultPipes);
 	t.fused_bounces = flag("ADYPT_FUSED_BOUNCES", 1); t.first_fused = flag("ADYPT_FIRST_FUSED", 1); t.single_fused = flag("ADYPT_SINGLE_FUSED", 1);
-	t.gen_deal = flag("ADYPT_GEN_DEAL", 1); t.shade_bin = flag("ADYPT_SHADE_BIN", 0);
+	t.gen_deal = flag("ADYPT_GEN_DEAL", 1); t.shade_bin = flag("ADYPT_SHADE_BIN", 0); t.single_overlap = flag("ADYPT_SINGLE_OVERLAP", 1);
 	t.refill_min = (int)num("ADYPT_REFILL_MIN", 1, 64, 0); t.refill_min_primary = (int)num("ADYPT_REFILL_MIN_PRIMARY", 1, 64, 0);
 	t.bite = (int)num("ADYPT_BITE", 1, 4096, 0); t.bite_primary = (int)num("ADYPT_BITE_PRIMARY", 1, 4096, 0);
 	t.chunk = (int)num("ADYPT_CHUNK", 16, 4096, 0); t.endgame = (int)num("ADYPT_ENDGAME", 0, 1024, -1);
@@ -855,6 +982,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 	for(int k = 1; k < kMaxPipes; ++k) HIP_CREATE(hipStreamCreateWithFlags(&c->pipes[k].stream, hipStreamNonBlocking));
 	for(int k = 0; k < kMaxPipes; ++k) HIP_CREATE(hipEventCreateWithFlags(&c->pipes[k].done, hipEventDisableTiming));
 	HIP_CREATE(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+	for(int s = 0; s < 2; ++s) HIP_CREATE(hipEventCreateWithFlags(&c->roll_ready[s], hipEventDisableTiming));
 	c->tun = read_tunables();
 	c->pipeline = c->tun.pipeline;
 	hipDeviceProp_t prop;
@@ -866,7 +994,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		if(t.refill_min > 0) c->refill_min = c->refill_min_primary = (uint32_t)t.refill_min;
 		if(t.refill_min_primary > 0) c->refill_min_primary = (uint32_t)t.refill_min_primary;
 		c->deal_chunks = t.gen_deal; c->first_fused = t.first_fused; c->fused_bounces = t.fused_bounces; c->single_fused = t.single_fused;
-		c->audit_selftest = t.audit_selftest;
+		c->audit_selftest = t.audit_selftest; c->single_overlap = t.single_overlap;
 		if(t.shade_min > 0) c->shade_min = (uint32_t)t.shade_min;
 		if(t.chunk > 0) c->chunk = (uint32_t)t.chunk;
 		if(t.endgame >= 0) c->endgame = (uint32_t)t.endgame;
@@ -1047,6 +1175,7 @@ void adypt_destroy(adypt_ctx *c)
 	}
 	if(c->h_overflow) (void)hipHostFree(c->h_overflow);
 	if(c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+	for(int s = 0; s < 2; ++s) if(c->roll_ready[s]) (void)hipEventDestroy(c->roll_ready[s]);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -1262,6 +1391,15 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		// asked for are simply finished early and parked; later calls hand them out one running-mean step at a time.
 		const int m = c->lookahead ? c->frames_in_flight : std::min(remaining, c->frames_in_flight);
 		const int hand_out = std::min(remaining, m);
+		// One frame per pass through the one-launch pipeline: a rolling single frame (frame k + 1 is enqueued under the end of frame k's k_path)
+		if(m == 1 && c->single_fused && c->first_fused && c->fused_bounces && !c->sun_visibility && (int64_t)c->n_local_px <= kPathMaxPaths)
+		{
+			int r = trace_rolling_frame(c, sc, px, stats, remaining > 1);
+			if(r != ADYPT_OK) return r;
+			remaining -= 1;
+			continue;
+		}
+		drop_rolling(c); // (a batch works in the whole queues)
 		const int first_retrace = (life - c->spp % life) % life;                       // batch index of the first re-tracing frame
 		const int n_retrace = first_retrace < m ? (m - 1 - first_retrace) / life + 1 : 0;
 		const int n_groups = (c->spp + m - 1) / life - c->spp / life + 1;
@@ -1274,20 +1412,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		if(c->sun_visibility) { int r = ensure_shadow_queue(c); if(r != ADYPT_OK) return r; }
 		FrameArgs f;
 		fill_frame(c, &f);
-		{
-			// Sobol::Next (src/Util/Sobol.cpp:16-21) for the m frames of the batch
-			const int slot = c->sobol_next;
-			c->sobol_next = (slot + 1) % adypt_ctx::kSobolSlots;
-			HIP_TRY(c, hipEventSynchronize(c->sobol_done[slot])); // the copy that last used this slot has left it
-			std::vector<float> pts((size_t)m * 2 * max_bounce);
-			int r = adypt_sobol_points(2 * max_bounce, c->spp, m, pts.data());
-			if(r != ADYPT_OK) return fail(c, r, adypt_host_last_error());
-			float *padded = c->h_sobol[slot];
-			memset(padded, 0, (size_t)m * 64 * sizeof(float));
-			for(int k = 0; k < m; ++k) memcpy(&padded[(size_t)k * 64], &pts[(size_t)k * 2 * max_bounce], sizeof(float) * 2 * (size_t)max_bounce);
-			HIP_TRY(c, hipMemcpyAsync(c->d_sobol, padded, (size_t)m * 64 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-			HIP_TRY(c, hipEventRecord(c->sobol_done[slot], c->stream));
-		}
+		{ int r = upload_sobol(c, c->spp, m, c->d_sobol); if(r != ADYPT_OK) return r; } // Sobol::Next (src/Util/Sobol.cpp:16-21) for the m frames of the batch
 		// A single frame (no look-ahead, or one frame in flight) runs as a batch of one — camera launch, k_shade_first, k_path, k_resolve: 4 launches
 		// instead of 1 + 2 x maxBounce — whenever a batch would take the one-launch pipeline (ADYPT_SINGLE_FUSED=0: the launch-per-bounce frame)
 		const bool as_batch = m > 1 || (c->single_fused && c->first_fused && c->fused_bounces && !c->sun_visibility && (int64_t)c->n_local_px <= kPathMaxPaths);
@@ -1485,6 +1610,7 @@ static int trace_rays_impl(adypt_ctx *c, const float *rays, int64_t n, adypt_hit
 	if(!c || n < 0 || (n > 0 && (!rays || !hits))) return ADYPT_E_INVALID;
 	if(!c->queues_ok) return fail(c, ADYPT_E_STATE, "adypt_trace_rays: the context lost its ray queues (failed adypt_set_frames_in_flight)");
 	HIP_TRY(c, hipSetDevice(c->device));
+	drop_rolling(c); // (a frame started ahead works in a window of the queues this call is about to fill)
 	if(!c->pt_started) { int r = apply_params(c); if(r != ADYPT_OK) return r; }
 	if(with_stats) { int r = ensure_ray_stats(c); if(r != ADYPT_OK) return r; }
 	std::vector<float4> o, d, h;

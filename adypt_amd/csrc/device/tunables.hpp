@@ -7,6 +7,7 @@
 //   ADYPT_FUSED_BOUNCES           fused_bounces          0/1            1         bounces 1.. of a batch in one k_path launch (adypt_set_fused_bounces)
 //   ADYPT_FIRST_FUSED             first_fused            0/1            1         camera ray + bounce 0 in k_shade_first
 //   ADYPT_SINGLE_FUSED            single_fused           0/1            1         a single frame runs as a batch of one through k_path
+//   ADYPT_SINGLE_OVERLAP          single_overlap         0/1            1         single frames in a row: frame k + 1 is enqueued on a second stream under the end of frame k's k_path
 //   ADYPT_GEN_DEAL                gen_deal               0/1            1         new paths dealt to the 8 queue segments in 256-path chunks
 //   ADYPT_SHADE_BIN               shade_bin              0/1            0         k_shade bins by material class (measured slower)
 //   ADYPT_REFILL_MIN              refill_min             1..64          16        idle lanes at which a wave refills (secondary rays)
@@ -39,7 +40,7 @@ namespace adypt {
 struct Tunables {
 	int frames_in_flight = 0;       // 0 = automatic
 	int pipeline = 1;
-	int fused_bounces = 1, first_fused = 1, single_fused = 1, gen_deal = 1, shade_bin = 0;
+	int fused_bounces = 1, first_fused = 1, single_fused = 1, single_overlap = 1, gen_deal = 1, shade_bin = 0;
 	int refill_min = 0, refill_min_primary = 0, bite = 0, bite_primary = 0, chunk = 0, endgame = -1, shade_min = 0; // 0 (endgame: -1) = the built-in default
 	int lds_stack_depth = 0, trace_blocks_per_cu = 0, path_blocks_per_cu = 0, path_lds_depth = 0, path_verbose = 0;
 	long ref_triangles_max_mb = -1; // -1 = automatic

@@ -54,12 +54,12 @@ rep("""				asm volatile("; ADYPT_MARK exchange_end");
 				if(do_shade) pf_shade += __builtin_readcyclecounter() - pf_s0;
 				pf_exch += __builtin_readcyclecounter() - pf_t0;
 """)
-rep("""			__builtin_amdgcn_s_sleep(8);
-			continue;
-""", """			{ const unsigned long long i0 = __builtin_readcyclecounter();
-			__builtin_amdgcn_s_sleep(8);
-			pf_idle += __builtin_readcyclecounter() - i0; }
-			continue;
+rep("""				__builtin_amdgcn_s_sleep(8);
+				skip_trip = true;
+""", """				{ const unsigned long long i0 = __builtin_readcyclecounter();
+				__builtin_amdgcn_s_sleep(8);
+				pf_idle += __builtin_readcyclecounter() - i0; }
+				skip_trip = true;
 """)
 rep("""				if(gn == 0) break;
 				for(uint32_t i = (uint32_t)lane; i < gn; i += 64u) init_idx[have + i] = gb + i;
@@ -75,10 +75,14 @@ rep("""	const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 =
 """, """	const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 	if(threadIdx.x == 0) atomicCAS(&a.stats->path_hits, 0ull, clk_r0);
 """)
-rep("""#include "traverse_trip.inc"
-	}
-""", """		pf_trips += 1; pf_trip_lanes += (uint32_t)__popcll(live);
+rep("""		if(!skip_trip)
 #include "traverse_trip.inc"
+	}
+""", """		if(!skip_trip)
+		{
+		pf_trips += 1; pf_trip_lanes += (uint32_t)__popcll(live);
+#include "traverse_trip.inc"
+		}
 	}
 	if(lane == 0)
 	{

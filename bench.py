@@ -550,12 +550,34 @@ def main() -> None:
             pt.Trace(True, 16)
             pt.ResetStats()
             t1 = time.perf_counter()
-            pt.Trace(True, 16)
+            pt.Trace(True, 16)       # one call, 16 frames, one frame per pass: consecutive frames overlap on two streams (no frame is traced that was not asked for)
             dt0 = time.perf_counter() - t1
             s0 = pt.GetStats()
+            pt.ResetStats()
+            t1 = time.perf_counter()
+            for _ in range(32):
+                pt.Trace(True, 1)    # one SYNCHRONOUS call per frame, nothing traced ahead: each frame's launch end is paid in full
+            dt2 = time.perf_counter() - t1
+            s2 = pt.GetStats()
+            pt.SetLookahead(True)    # one call per frame, one frame started ahead on the second stream (dropped if the camera moves)
+            pt.Trace(True, 2)
+            pt.ResetStats()
+            pt.DeviceSynchronize()
+            t1 = time.perf_counter()
+            for _ in range(32):
+                pt.Trace(True, 1)
+            pt.DeviceSynchronize()
+            dt3 = time.perf_counter() - t1
+            s3 = pt.GetStats()
+            pt.SetLookahead(False)
             single = {"calls": n_calls, "ms_per_call": round(dt * 1e3 / n_calls, 4), "Mrays_s": round(s1["rays"] / dt / 1e6, 1),
                       "frac_of_batched": round((s1["rays"] / dt) / (total_rays / elapsed), 3),
                       "without_lookahead_Mrays_s": round(s0["rays"] / dt0 / 1e6, 1),
+                      "one_frame_per_pass": {"one_call_of_16_frames_Mrays_s": round(s0["rays"] / dt0 / 1e6, 1),
+                                             "one_synchronous_call_per_frame_Mrays_s": round(s2["rays"] / dt2 / 1e6, 1),
+                                             "one_call_per_frame_one_frame_started_ahead_Mrays_s": round(s3["rays"] / dt3 / 1e6, 1),
+                                             "note": "frames_in_flight 1.  Consecutive single frames run on two streams: frame k + 1's bounce 0 and k_path are enqueued under the end of frame k's "
+                                                     "k_path — within a call that asks for several frames, and across calls with adypt_set_lookahead (one frame ahead, same tmpLifetime group only)"},
                       "note": "adypt_trace_spp(ctx, 1) per call, adypt_set_lookahead on: a call that needs untraced frames traces a whole pass of %d, the following calls only apply their running-mean step" % fif}
 
         # ---- the kernel where memory binds, and the CPU baseline ----------------------------------------------------------------------

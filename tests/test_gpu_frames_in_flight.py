@@ -236,3 +236,68 @@ def test_shade_binning_option_and_shader_clock(scene_cache, sobol_matrices, monk
     ghz = p.GetShaderClockGHz()
     assert 0.8 < ghz < 3.0, ghz
     p.destroy()
+
+
+@pytest.mark.parametrize("name,w,h,life,fif,lookahead", [("tiny0", 100, 75, 4, 1, False), ("tiny0", 100, 75, 4, 1, True), ("tiny0", 96, 64, 3, 8, False),
+                                                          ("sibenik", 160, 90, 2, 1, True), ("tiny0", 72, 40, 1, 1, True)])
+def test_single_frames_in_a_row_overlap_and_stay_bit_exact(name, w, h, life, fif, lookahead, scene_cache, sobol_matrices, monkeypatch):
+    """One frame per wavefront pass (Instance::Update's Trace(true) per window frame, src/Instance.cpp:44-57, without a pass traced ahead): frame k + 1's
+    bounce 0 and k_path are enqueued on a second stream under the END of frame k's k_path — inside a call that asks for several frames, and across calls
+    when look-ahead is on (one frame ahead, never across a tmpLifetime boundary).  After EVERY call image, spp and image 1 are the oracle's; traversal
+    stacks spill out of LDS (two frames' launches overlap: their spill arrays must be their own); a camera change, a ray batch in between and a reset
+    drop the frame started ahead; ADYPT_SINGLE_OVERLAP=0 (strictly one after the other) gives the same bits."""
+    monkeypatch.setenv("ADYPT_LDS_STACK_DEPTH", "2")
+    inst = _instance(scene_cache, name, w, h, {"tmpLifetime": life, "maxBounce": 6, "subpixel": 3})
+    c, p = inst.m_config.c, inst.m_path_tracer
+    osc, P = oracle_scene_from_instance(inst), oracle_params_from_config(c)
+    shift = O.shift_bytes(31, c.width, c.height)
+    p.SetFramesInFlight(fif)
+    p.SetLookahead(lookahead)
+    state = O.PathTracerState(c.width, c.height)
+
+    def step(n, tag):
+        p.Trace(True, n)
+        O.pt_frames(osc, P, shift, sobol_matrices, state, n)
+        assert p.GetSPP() == state.spp
+        assert np.array_equal(bits(p.ReadResult()), bits(state.accum[..., :3])), tag
+        tri, uv = p.ReadHits()
+        assert np.array_equal(tri, state.cache_tri), "image 1, " + tag
+        m = tri >= 0
+        assert np.array_equal(bits(uv)[m], bits(state.cache_uv)[m]), "image 1 uv, " + tag
+
+    for k in range(2 * life + 3):          # one frame per call, across tmpLifetime boundaries
+        step(1, "call %d" % k)
+    if fif == 1:
+        step(5, "five frames in one call")  # frames overlap inside the call
+    assert p.GetFusedBounces()
+    # a batch of rays through the same queues between two frames (drops a frame started ahead)
+    rays = np.zeros((64, 8), np.float32)
+    rays[:, 0:3] = np.asarray(c.position, np.float32); rays[:, 3] = c.ray_tmin
+    rays[:, 4:7] = np.random.default_rng(5).normal(size=(64, 3)).astype(np.float32)
+    h1 = p.TraceRays(rays, with_stats=False)
+    step(1, "after a ray batch")
+    h2 = p.TraceRays(rays, with_stats=False)
+    assert np.array_equal(h1["ref_idx"], h2["ref_idx"])
+    # a camera change: the frame started ahead saw the old camera and must not be used
+    step(1, "before the camera change")
+    ip, iv = O.camera(c.fov + 5.0, c.yaw - 9.0, c.pitch + 2.0, c.width, c.height)
+    p.SetCamera(ip, iv, list(c.position))
+    P = O.make_params(c.width, c.height, list(c.position), ip, iv, stack_size=c.stack_size, max_bounce=c.max_bounce, subpixel=c.subpixel,
+                      tmp_life=c.tmp_lifetime, tmin=c.ray_tmin, clamp=c.clamp, sun=list(c.sun))
+    for k in range(life + 2):
+        step(1, "after the camera change, frame %d" % k)
+    # a reset restarts the sequence; strictly serial frames give the same bits
+    p.Reset()
+    state = O.PathTracerState(c.width, c.height)
+    step(3, "after reset")
+    img = p.ReadResult()
+    p.destroy()
+    monkeypatch.setenv("ADYPT_SINGLE_OVERLAP", "0")
+    inst2 = _instance(scene_cache, name, w, h, {"tmpLifetime": life, "maxBounce": 6, "subpixel": 3})
+    p2 = inst2.m_path_tracer
+    p2.SetFramesInFlight(fif)
+    p2.SetCamera(ip, iv, list(c.position))
+    for _ in range(3):
+        p2.Trace(True, 1)
+    assert np.array_equal(bits(p2.ReadResult()), bits(img))
+    p2.destroy()
