@@ -10,7 +10,10 @@ import sys
 d = sys.argv[1]
 import os
 COUNT = os.environ.get("ADYPT_BLOCKS_COUNT", "0") != "0"   # 0: marks only (static counts: tools/trip_budget.py); 1: marks + entry counters (tools/path_block_counts.py)
-NAMES = ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_push", "B_tri_load", "B_node_load", "C_woop", "D_slab", "E_flush"]
+SET = os.environ.get("ADYPT_BLOCKS_SET", "trip")           # trip: the blocks of the trip (default) | shade: the blocks inside a shading round (a second counting pass:
+                                                            # there are twelve counters)
+NAMES = ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_push", "B_tri_load", "B_node_load", "C_woop", "D_slab", "E_flush"] if SET == "trip" else \
+        ["shade", "S_parked", "S_miss", "S_surface", "S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric", "S_dead", "S_alive", "S_replace"]
 # Counters: a value that is modified inside a divergent block cannot live in an SGPR the compiler allocates (the merge after the block is per lane).
 # So k_path is held to 96 SGPRs (amdgpu_num_sgpr) and the counters live in s96 .. s101, touched only by inline assembly: two 16-bit counters per
 # register (a wave makes < 65536 trips per launch at the batch sizes measured).
@@ -37,7 +40,7 @@ def leave(n):
     return '__builtin_amdgcn_sched_barrier(0); asm volatile("; ADYPT_MARK %s_end"); __builtin_amdgcn_sched_barrier(0);' % n
 
 
-edit("traverse_trip.inc", [
+TRIP_EDITS = [
     ("			const bool can_pop = !pending && ng_y <= 0x00ffffffu && sp != 0;", "			asm volatile(\"; ADYPT_MARK sec_A\");\n			const bool can_pop = !pending && ng_y <= 0x00ffffffu && sp != 0;"),
     ("			auto swap1 = [](uint32_t v)", "			asm volatile(\"; ADYPT_MARK sec_B\");\n			auto swap1 = [](uint32_t v)"),
     ("			float tt, tu, tv;\n", "			asm volatile(\"; ADYPT_MARK sec_C\");\n			float tt, tu, tv;\n"),
@@ -61,16 +64,44 @@ edit("traverse_trip.inc", [
     ("				tg_y = hitmask & 0x00ffffffu;\n			}", "				tg_y = hitmask & 0x00ffffffu;\n				" + leave("D_slab") + "\n			}"),
     ("				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert", "				" + enter("E_flush") + "\n				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert"),
     ("				active = false;\n			}\n		}", "				active = false;\n				" + leave("E_flush") + "\n			}\n		}"),
-])
+]
+if SET == "trip":
+    edit("traverse_trip.inc", TRIP_EDITS)
 # (k_trace includes the trip too: it gets a dummy counter array)
 zero = " ".join('asm volatile("s_mov_b32 s%d, 0" ::: "s%d");' % (r, r) for r in range(96, 102))
 read = " ".join('asm volatile("s_mov_b32 %%0, s%d" : "=s"(bc[%d]));' % (96 + i, i) for i in range(6))
-pairs = [
+SHADE_PATH = [
+    ("						if(parked) { const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); }", "						if(parked) { " + enter("S_parked") + " const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); " + leave("S_parked") + " }"),
+    ("							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135\n							alive = false;",
+     "							" + enter("S_miss") + "\n							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135\n							alive = false;\n							" + leave("S_miss")),
+    ("							if(a.tri_remap) tri_idx = a.tri_remap[tri_idx];", "							" + enter("S_surface") + "\n							if(a.tri_remap) tri_idx = a.tri_remap[tri_idx];"),
+    ("								alive = respond(f, si, rng, b, dir, color, ret);\n							}\n						}", "								alive = respond(f, si, rng, b, dir, color, ret);\n							}\n							" + leave("S_surface") + "\n						}"),
+    ("						if(!alive) // main()'s clamp (pathtracer.glsl:224); the running mean is k_resolve's, in frame order (a k_path pass is always batched)\n							f.done[pi] = make_float4(gl_min(ret.x, f.clamp), gl_min(ret.y, f.clamp), gl_min(ret.z, f.clamp), 1.0f);",
+     "						if(!alive) { " + enter("S_dead") + "\n							f.done[pi] = make_float4(gl_min(ret.x, f.clamp), gl_min(ret.y, f.clamp), gl_min(ret.z, f.clamp), 1.0f); " + leave("S_dead") + " }"),
+    ("					if(alive)\n					{\n						if(__float_as_uint(ret.x) != __float_as_uint(ret_in.x)", "					if(alive)\n					{\n						" + enter("S_alive") + "\n						if(__float_as_uint(ret.x) != __float_as_uint(ret_in.x)"),
+    ("						tab[T_OX * kPathSlots + sslot] = __float_as_uint(origin.x); tab[T_OY * kPathSlots + sslot] = __float_as_uint(origin.y); tab[T_OZ * kPathSlots + sslot] = __float_as_uint(origin.z);\n					}\n					// ---------------- paths that ended",
+     "						tab[T_OX * kPathSlots + sslot] = __float_as_uint(origin.x); tab[T_OY * kPathSlots + sslot] = __float_as_uint(origin.y); tab[T_OZ * kPathSlots + sslot] = __float_as_uint(origin.z);\n						" + leave("S_alive") + "\n					}\n					// ---------------- paths that ended"),
+    ("					if(repl) load_path(a, idx, sslot);", "					if(repl) { " + enter("S_replace") + " load_path(a, idx, sslot); " + leave("S_replace") + " }"),
+]
+SHADE_HPP = [
+    ("		if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) s.diffuse = textured_diffuse(sc, tri_idx, tex_desc, tu, tv, w);\n		else s.diffuse = f3(md.y, md.z, md.w);\n		s.specular = f3(ms.y, ms.z, ms.w);",
+     "		if(f.n_tex != 0 && dtex != -1 && dtex >= 0 && dtex < f.n_tex) { " + enter("S_textured") + " s.diffuse = textured_diffuse(sc, tri_idx, tex_desc, tu, tv, w); " + leave("S_textured") + " }\n		else s.diffuse = f3(md.y, md.z, md.w);\n		s.specular = f3(ms.y, ms.z, ms.w);"),
+    ("		if(e > 0.3f)\n		{\n			const F3 r = reflect3(dir, normal), shv = sample_hemisphere(rng, b, e);", "		if(e > 0.3f)\n		{\n			" + enter("S_glossy") + "\n			const F3 r = reflect3(dir, normal), shv = sample_hemisphere(rng, b, e);"),
+    ("			done = true;\n		}\n		else illum = 1;", "			done = true;\n			" + leave("S_glossy") + "\n		}\n		else illum = 1;"),
+    ("		if(illum == 1)\n		{\n			dir = align_direction(sample_hemisphere(rng, b, 0.0f), normal);\n			color = color * diffuse;\n		}",
+     "		if(illum == 1)\n		{\n			" + enter("S_diffuse") + "\n			dir = align_direction(sample_hemisphere(rng, b, 0.0f), normal);\n			color = color * diffuse;\n			" + leave("S_diffuse") + "\n		}"),
+    ("		else if(illum >= 3 && illum <= 5)\n		{\n			color = color * specular;\n			dir = reflect3(dir, normal);\n		}",
+     "		else if(illum >= 3 && illum <= 5)\n		{\n			" + enter("S_mirror") + "\n			color = color * specular;\n			dir = reflect3(dir, normal);\n			" + leave("S_mirror") + "\n		}"),
+    ("		else if(illum == 6 || illum == 7)\n		{\n			float eta = ior;", "		else if(illum == 6 || illum == 7)\n		{\n			" + enter("S_dielectric") + "\n			float eta = ior;"),
+    ("			else dir = reflect3(dir, normal);\n		}\n	}\n	if(b + 1 >= f.max_bounce) alive = false; // last loop iteration", "			else dir = reflect3(dir, normal);\n			" + leave("S_dielectric") + "\n		}\n	}\n	if(b + 1 >= f.max_bounce) alive = false; // last loop iteration"),
+]
+if SET == "shade":
+    edit("shade.hpp", SHADE_HPP)
+pairs = (SHADE_PATH if SET == "shade" else []) + [
     ('				asm volatile("; ADYPT_MARK exchange_begin");', "				" + enter("exchange")),
     ('					asm volatile("; ADYPT_MARK shade_begin");', "					" + enter("shade")),
     ('			asm volatile("; ADYPT_MARK setup_begin");', "			" + enter("setup")),
-    ("		if(!skip_trip)\n#include \"traverse_trip.inc\"", "		if(!skip_trip)\n		{\n		" + enter("trip") + "\n#include \"traverse_trip.inc\"\n		" + leave("trip") + "\n		}"),
-]
+] + ([("		if(!skip_trip)\n#include \"traverse_trip.inc\"", "		if(!skip_trip)\n		{\n		" + enter("trip") + "\n#include \"traverse_trip.inc\"\n		" + leave("trip") + "\n		}")] if SET == "trip" else [])
 if COUNT:
     pairs += [
         ("template <bool STATS>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathKernArgs K)\n{",

@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec)
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
 NOMINAL_CLOCK_GHZ = 2.4 # only used when no profile supplies the clock the chip really ran the kernel at
-PMC_BENCH, PMC_SANMIGUEL, ISSUE_MODEL = "r4_pmc_bench.json", "r4_pmc_sanmiguel.json", "r4_valu_issue_model.json"
+PMC_BENCH, PMC_SANMIGUEL, ISSUE_MODEL, GATHER_ROOF = "r5_pmc_bench.json", "r5_pmc_sanmiguel.json", "r5_valu_issue_model.json", "r5_gather_roof.json"
 PT_CFG = {"maxBounce": 8, "subpixel": 8, "clamp": 4.0, "sun": [12.0, 11.0, 10.0], "stackSize": 24}
 SEED = 12345
 
@@ -101,6 +101,11 @@ def valu_roofline(pmc, model, kernel_rays_s, live_clock_ghz=0.0):
         loops = model["avg_issue_cycles_per_inst_single_class_loops"]
         out["issue_cycles_per_inst_single_class_loops"] = loops
         out["frac_at_single_class_loop_rates"] = round(inst_rate * loops / 1e9 / peak, 4)
+        # the two rate tables bracket the truth: a mixed stream issues faster than the weighted sum of one-instruction loops, never faster than the architectural rates
+        out["frac_range"] = [out["frac"], out["frac_at_single_class_loop_rates"]]
+        out["mix_weighted_by"] = "executed instructions (block entries of the counting variant x static counts): profiles/%s" % ISSUE_MODEL
+        if "model_over_measured" in model:
+            out["mix_reproduces_SQ_INSTS_VALU_within"] = round(abs(model["model_over_measured"] - 1.0), 4)
         if "vmem_rd_insts_per_ray" in pmc:  # the co-limiter: the CU's one vector-memory pipeline (profiles/r2_ablations_k_trace.txt)
             out["vmem_busy_est"] = round(pmc["vmem_rd_insts_per_ray"] * kernel_rays_s * model["vmem_cycles_per_load_inst"] / (256 * (clock or NOMINAL_CLOCK_GHZ) * 1e9), 3)
     return out
@@ -148,7 +153,23 @@ def census(pt, steps, warmup, expect_rays=None):
     return cs
 
 
-def roofline_block(dom, cs, pmc_name, live_clock, bvh_mb, note_extra=""):
+def gather_roof(resident_mb):
+    """Fabric-side GB/s that k_path's own access pattern — every lane chasing dependent, uniformly random 80-byte records, k_path's launch shape
+    (6 workgroups of 4 waves per CU) — sustains on a table of about the scene's resident size (profiles/r5_gather_roof.json, tools/microbench/gather_roof.hip)."""
+    g = load_profile(GATHER_ROOF)
+    if not g:
+        return None
+    rows = [r for r in g["configs"] if r["record_B"] == 80 and r["wgs_per_cu"] == 6 and r["chains"] == 1 and "fabric_B_per_record" in r]
+    if not rows:
+        return None
+    r = min(rows, key=lambda x: abs(x["table_MiB"] - resident_mb))
+    return {"gather_roof_GBs": round(r["Grecords_s"] * r["fabric_B_per_record"], 1), "gather_roof_useful_GBs": r["useful_GBs"], "gather_roof_table_MiB": r["table_MiB"],
+            "gather_roof_fabric_B_per_80B_record": r["fabric_B_per_record"], "gather_roof_l2_hit_rate": r.get("l2_hit_rate"),
+            "gather_roof_utcl1_miss_per_record": (r.get("translation_per_record") or {}).get("TCP_UTCL1_TRANSLATION_MISS_sum"),
+            "gather_roof_fabric_read_latency_cycles": r.get("fabric_read_latency_cycles")}
+
+
+def roofline_block(dom, cs, pmc_name, live_clock, bvh_mb, note_extra="", binds="valu_issue"):
     """The contract's roofline object for the dominant kernel (`dom`: name, HIP-event ms, launches, rays of the timed region; `cs`: census)."""
     ms, launches, rays = dom["ms"], max(1, dom["launches"]), dom["rays"]
     rays_s = rays / (ms * 1e-3) if ms > 0 else 0.0
@@ -164,7 +185,9 @@ def roofline_block(dom, cs, pmc_name, live_clock, bvh_mb, note_extra=""):
         pmc, why = None, "profiles/%s holds %s, this run's dominant kernel is %s" % (pmc_name, pmc.get("kernel"), dom["kernel"])
     if pmc:
         out.update(traffic_fields(pmc, rays, launches, rays_s))
-        out.update({"achieved": out["traffic_GBs"], "frac": out["traffic_frac_of_hbm_peak"], "pmc_stale": False,
+        out.update({"achieved": out["traffic_GBs"], "frac": out["traffic_frac_of_hbm_peak"], "pmc_stale": False, "bound": binds,
+                    "frac_of": "fabric traffic (PMC FETCH_SIZE x 2 + WRITE_SIZE per ray, committed profile replayed against this run's live rays/s) / 8 TB/s HBM peak; "
+                               "`bound` names what binds the kernel, which on this scene is NOT this resource: see valu_issue",
                     "traffic_over_algorithmic": round(pmc["traffic_bytes_per_ray"] / (cs["k_alg_bytes"] / max(1, cs["k_rays"])), 3),
                     "valu_issue": valu_roofline(pmc, load_profile(ISSUE_MODEL), rays_s, live_clock),
                     "note": "achieved / frac / traffic = fabric-side bytes of this kernel's launches (PMC FETCH_SIZE x 2 + WRITE_SIZE per ray, %s) x this run's "
@@ -201,13 +224,18 @@ def hbm_resident_block(args, dev):
     live_clock = pt.GetShaderClockGHz()
     cs = census(pt, steps, warmup, st["rays"])
     bvh_mb = (len(inst.bvh.nodes) + len(inst.bvh.tri_indices) * 52) / 1e6
-    out = roofline_block(dict(dominant(st), rays_warmup=warm["rays"]), cs, PMC_SANMIGUEL, live_clock, bvh_mb)
+    out = roofline_block(dict(dominant(st), rays_warmup=warm["rays"]), cs, PMC_SANMIGUEL, live_clock, bvh_mb, binds="memory latency (between hbm and valu_issue)")
+    # the roof of THIS access pattern: random dependent gathers of small records from a table of the scene's resident size (BVH + the per-reference triangle copy)
+    resident_mb = bvh_mb + len(inst.bvh.tri_indices) * 128 / 1e6
+    gr = gather_roof(resident_mb / 1.048576)
+    if gr and out.get("traffic_GBs"):
+        out.update(gr)
+        out["frac_of_gather_roof"] = round(out["traffic_GBs"] / gr["gather_roof_GBs"], 4)
+        out["resident_MB"] = round(resident_mb)
     out.update({"workload": "sanmiguel-like procedural stand-in (%s), %d triangles, BVH %.0f MB (nodes + Woop + index) > 256 MB Infinity Cache, 1920x1080, 8 bounces, %d frames after %d warm-up"
                             % (spec.label, inst.scene.n_tris, bvh_mb, steps, warmup),
                 "whole_frame_Mrays_s": round(st["rays"] / wall / 1e6, 1), "trace_kernels_ms": round(st["trace_ms"], 2), "other_kernels_ms": round(st["shade_ms"], 2),
                 "setup_s": round(setup_s, 1)})
-    if "valu_issue" in out:
-        out["bound"] = "between hbm and valu_issue"
     pt.destroy()
     return out
 

@@ -65,6 +65,19 @@ out = {
     "source_hash": device_source_hash(),
     "note": "fabric-side bytes (Infinity-Cache hits are counted, MI355X_MICROARCH.md)",
 }
+# translation and fabric-side latency (VERDICT r4 task 1): per vector-memory read instruction / per fabric read
+utcl_req, utcl_miss, utcl_mum = per_kernel("TCP_UTCL1_REQUEST_sum"), per_kernel("TCP_UTCL1_TRANSLATION_MISS_sum"), per_kernel("TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum")
+ea_level, ea_req, ea_dram = per_kernel("TCC_EA0_RDREQ_LEVEL_sum"), per_kernel("TCC_EA0_RDREQ_sum"), per_kernel("TCC_EA0_RDREQ_DRAM_sum")
+l1_lat, l1_req = per_kernel("TCP_TCC_READ_REQ_LATENCY_sum"), per_kernel("TCP_TCC_READ_REQ_sum")
+if utcl_req:
+    out["utcl1_requests_per_ray"] = sum(utcl_req) / max(1, rays)
+    out["utcl1_translation_miss_per_request"] = sum(utcl_miss) / max(1.0, sum(utcl_req))
+    out["utcl1_translation_miss_under_miss_per_request"] = sum(utcl_mum) / max(1.0, sum(utcl_req))
+if ea_level and ea_req:
+    out["fabric_read_latency_cycles"] = sum(ea_level) / max(1.0, sum(ea_req))  # requests in flight summed per cycle / requests
+    out["fabric_reads_from_dram_frac"] = sum(ea_dram) / max(1.0, sum(ea_req)) if ea_dram else None
+if l1_lat and l1_req:
+    out["l1_to_l2_read_latency_cycles"] = sum(l1_lat) / max(1.0, sum(l1_req))
 if phases:
     if "timed_avg_launch_ms" in phases:
         out["avg_launch_ms_kernel_trace"] = phases["timed_avg_launch_ms"]

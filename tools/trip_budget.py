@@ -62,18 +62,44 @@ def count(lines):
     return {"valu": sum(ops.values()), "by_class": dict(cls), "by_opcode": dict(sorted(ops.items(), key=lambda kv: -kv[1]))}
 
 
-def main():
-    flags = hipflags()
+def marked_build(flags, block_set):
     with tempfile.TemporaryDirectory() as t:
         # (a sibling directory two levels below: the sources include ../../../include/adypt_hip.h)
         dev = os.path.join(t, "a", "b", "device")
         os.makedirs(os.path.dirname(dev))
         shutil.copytree(os.path.join(CSRC, "device"), dev)
         shutil.copytree(os.path.join(ROOT, "include"), os.path.join(t, "include"))
-        subprocess.check_call([sys.executable, os.path.join(CSRC, "measure", "k_path_blocks.py"), dev], env=dict(os.environ, ADYPT_BLOCKS_COUNT="0"))
+        subprocess.check_call([sys.executable, os.path.join(CSRC, "measure", "k_path_blocks.py"), dev], env=dict(os.environ, ADYPT_BLOCKS_COUNT="0", ADYPT_BLOCKS_SET=block_set))
         out = os.path.join(t, "marked.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DADYPT_BUILD", "--cuda-device-only", "-S", os.path.join(dev, "tracer.hip"), "-o", out], stderr=subprocess.DEVNULL)
-        marked = body_of(open(out).read())
+        return body_of(open(out).read())
+
+
+def shade_blocks(flags):
+    """the blocks INSIDE a shading round (second marked build): what runs every round, and what only when some lane needs it"""
+    lines = marked_build(flags, "shade")
+    marks = {}
+    for i, l in enumerate(lines):
+        m = re.search(r"ADYPT_MARK (\w+)", l)
+        if m:
+            marks.setdefault(m.group(1), i)
+    names = ["S_parked", "S_miss", "S_surface", "S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric", "S_dead", "S_alive", "S_replace"]
+    span = {b: (marks[b + "_begin"], marks[b + "_end"]) for b in names}
+    inner = ["S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric"]  # nested in S_surface
+    per = {b: [] for b in names}
+    every = []
+    for i in range(marks["shade_begin"], marks["shade_end"]):
+        owner = next((b for b in inner if span[b][0] <= i < span[b][1]), None) or next((b for b in names if b not in inner and span[b][0] <= i < span[b][1]), None)
+        (per[owner] if owner else every).append(lines[i])
+    out = {"every round": count(every)}
+    out.update({b: count(per[b]) for b in names})
+    out["valu_static"] = sum(v["valu"] for v in out.values())
+    return out
+
+
+def main():
+    flags = hipflags()
+    marked = marked_build(flags, "trip")
     subprocess.check_call(["make", "-s", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     product = body_of(open(os.path.join(CSRC, "build", "tracer.s")).read())
 
@@ -124,6 +150,7 @@ def main():
         "trip_valu_static_marked_build": sum(v["valu_static"] for v in sections.values()),
         "trip_valu_static_product_build": count(product[pm["exchange_end"]:phi + 1])["valu"],
         "loop_outside_trip": dict(regions, **{"loop control outside every mark (votes, the exchange's condition)": count(rest)}),
+        "shading_round_blocks": shade_blocks(flags),
         "note": "valu = static count of vector-ALU instructions (v_readlane / v_writelane / v_readfirstlane excluded, as in SQ_INSTS_VALU's complement of scalar work they "
                 "are few).  by_class: full = 2-cycle fp32 / logic / move, normal = 4-cycle, packed64 = v_pk_* and 64-bit (4), trans = 8 (profiles/r3_valu_calibration.json)."}, indent=1))
 

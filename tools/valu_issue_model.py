@@ -1,38 +1,81 @@
-"""Build profiles/r4_valu_issue_model.json (read by bench.py) from the counter calibration (tools/valu_calibrate.sh ->
-profiles/r3_valu_calibration.json: TRUE shader cycles per wave-instruction per SIMD of one-instruction kernels) and the instruction
-mix of the dominant kernel's persistent loop (profiles/r4_k_path_instruction_mix.json, tools/instruction_mix.py).
-    python tools/valu_issue_model.py > profiles/r4_valu_issue_model.json"""
-import json, os
+"""Build profiles/r5_valu_issue_model.json (read by bench.py): the vector-ALU issue model of k_path<false>, weighted by EXECUTED instructions.
+
+  static counts   profiles/r5_trip_budget.json      tools/trip_budget.py: vector instructions per block of the persistent loop, by issue class (no GPU)
+  block entries   profiles/r5_k_path_block_counts.json   tools/path_block_counts.py: how often a wave enters each block (counting variant, GPU)
+  issue cycles    profiles/r3_valu_calibration.json  one-instruction loops: TRUE cycles a wave-instruction holds its SIMD's issue, per class
+  check           profiles/r5_pmc_bench.json         SQ_INSTS_VALU per ray of the product kernel (rocprofv3 --pmc, tools/collect_profiles.sh)
+
+executed instructions per wave-trip = sum over blocks (static x entries / trips); it must reproduce SQ_INSTS_VALU per wave-trip
+(= SQ_INSTS_VALU per ray / wave-trips per ray) within 3 % — tests/test_profiles_consistency.py asserts it.  Round 4's model weighted a static
+count of the whole loop and was off by 65 %.
+    python tools/valu_issue_model.py > profiles/r5_valu_issue_model.json"""
+import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cal = {r["kernel"]: r for r in json.load(open(ROOT + "/profiles/r3_valu_calibration.json"))["rows"]}
-mix = json.load(open(ROOT + "/profiles/r4_k_path_instruction_mix.json"))
+P = lambda n: os.path.join(ROOT, "profiles", n)
+cal = {r["kernel"]: r for r in json.load(open(P("r3_valu_calibration.json")))["rows"]}
+budget = json.load(open(P("r5_trip_budget.json")))
+counts = json.load(open(P("r5_k_path_block_counts.json")))
+pmc = json.load(open(P("r5_pmc_bench.json"))) if os.path.exists(P("r5_pmc_bench.json")) else None
+old = json.load(open(P("r4_k_path_instruction_mix.json")))
+
 CLASSES = [
-    ("normal rate (v_cvt_f32_ubyte, min/max/min3/max3, v_cmp, v_cndmask, bit-field, shifts, v_perm, ...)", "normal_rate_4_cycles", 4,
+    ("normal", "normal rate (v_cvt_f32_ubyte, min/max/min3/max3, v_cmp, v_cndmask, bit-field, shifts, v_perm, SDWA, DPP moves ...)", 4,
      ["k_cvt_ubyte", "k_max_f32", "k_min_f32", "k_max3_f32", "k_med3", "k_cmp", "k_cmp_sgpr", "k_cnd_sgpr", "k_bfe", "k_lshl", "k_lshl_or", "k_perm",
-      "k_and_or", "k_bfi", "k_lshl_add", "k_or3", "k_mul_lo", "k_div_fixup"]),
-    ("full rate (fp32 add/mul/fma, and/or/xor, integer add, arithmetic shift right, moves)", "full_rate_2_cycles", 2,
+      "k_and_or", "k_bfi", "k_lshl_add", "k_or3", "k_mul_lo", "k_div_fixup", "k_sdwa_cvt"]),
+    ("full", "full rate (fp32 add/mul/fma, and/or/xor, integer add, arithmetic shift right, moves)", 2,
      ["k_add_f32", "k_fma_f32", "k_mul_f32", "k_sub_f32", "k_and_b32", "k_or_b32", "k_xor_b32", "k_add_u32", "k_ashr", "k_mov"]),
-    ("packed fp32 (v_pk_fma_f32) / 64-bit", "packed_or_64bit_4_cycles", 4, ["k_pk_fma", "k_mad_u64"]),
-    ("transcendental (v_rcp_f32, v_sqrt_f32)", "transcendental_8_cycles", 8, ["k_rcp", "k_sqrt"]),
+    ("packed64", "packed fp32 (v_pk_fma_f32) / 64-bit", 4, ["k_pk_fma", "k_mad_u64"]),
+    ("trans", "transcendental (v_rcp_f32, v_sqrt_f32)", 8, ["k_rcp", "k_sqrt"]),
 ]
-classes, ideal, measured = [], 0.0, 0.0
-for name, key, architectural, kernels in CLASSES:
-    vals = [cal[k]["issue_cycles_per_inst_per_simd"] for k in kernels]
-    m = sum(vals) / len(vals)
-    share = mix["mix"][key]
-    classes.append({"class": name, "share": share, "cycles_architectural": architectural, "cycles_single_class_loop": round(m, 3),
-                    "single_class_loops": {k: cal[k]["issue_cycles_per_inst_per_simd"] for k in kernels}})
-    ideal += share * architectural
-    measured += share * m
-print(json.dumps({
-    "kernel": mix["kernel"],
-    "what": "shader cycles a wave-instruction holds its SIMD's vector-ALU issue, by class.  cycles_single_class_loop: profiles/r3_valu_calibration.json "
-            "(GRBM_GUI_ACTIVE / 8 of kernels that issue ONE kind of instruction from 5 waves per SIMD: true cycles, no assumed clock); "
-            "cycles_architectural: the 2 / 4 / 4 / 8 those loops approach.  share: the kernel's persistent loop (profiles/r4_k_path_instruction_mix.json; "
-            "tools/instruction_mix.py: static count over the persistent loop, the blocks that do not run every trip weighted by the in-kernel profile).",
-    "counter_note": "the same calibration shows SQ_ACTIVE_INST_VALU = 1 per instruction (2 per transcendental) whatever its issue time: "
-                    "x 4 it is NOT a busy-cycle count (a loop of full-rate instructions reads 1.63 'busy'), so bench.py no longer builds its roof on it",
+entries = counts["wave_entries"]
+trips = float(entries["trip"])
+w = {k: v / trips for k, v in entries.items()}  # entries per trip
+
+blocks = []  # (name, weight = executions per trip, static count object)
+for sec, body in budget["trip_sections"].items():
+    blocks.append(("trip %s: every trip" % sec, 1.0, body["always"]))
+    for b, c in body["blocks"].items():
+        blocks.append(("trip %s: %s" % (sec, b), w[b], c))
+lo = budget["loop_outside_trip"]
+blocks.append(("ray setup", w["setup"], lo["ray setup"]))
+blocks.append(("exchange", w["exchange"], lo["exchange (in front of a shading round)"]))
+blocks.append(("exchange, after the round", w["exchange"], lo["exchange (after a shading round / without one)"]))
+blocks.append(("shading round", w["shade"], lo["shading round"]))
+# loop control (votes, the exchange's condition): once per iteration = per trip + per iteration that skips the trip (a setup follows an exchange)
+rest_key = [k for k in lo if k.startswith("loop control")][0]
+blocks.append(("loop control", 1.0 + w["setup"], lo[rest_key]))
+
+per_class = {c[0]: 0.0 for c in CLASSES}
+rows, total = [], 0.0
+for name, weight, c in blocks:
+    ex = weight * c["valu"]
+    total += ex
+    for k, n in c.get("by_class", {}).items():
+        per_class[k] += weight * n
+    rows.append({"block": name, "static_valu": c["valu"], "executions_per_trip": round(weight, 4), "executed_valu_per_trip": round(ex, 1)})
+classes, arch, loops = [], 0.0, 0.0
+for key, label, cycles, kernels in CLASSES:
+    share = per_class[key] / total
+    m = sum(cal[k]["issue_cycles_per_inst_per_simd"] for k in kernels) / len(kernels)
+    classes.append({"class": label, "share": round(share, 4), "cycles_architectural": cycles, "cycles_single_class_loop": round(m, 3)})
+    arch += share * cycles
+    loops += share * m
+out = {
+    "kernel": "k_path<false>",
+    "what": __doc__.split("\n    python")[0],
+    "blocks": rows,
+    "executed_valu_per_wave_trip_model": round(total, 1),
+    "wave_trips_per_ray": counts["wave_trips_per_ray"],
     "classes": classes,
-    "avg_issue_cycles_per_inst_architectural": round(ideal, 3),
-    "avg_issue_cycles_per_inst_single_class_loops": round(measured, 3),
-    "vmem_cycles_per_load_inst": mix["vmem_cycles_per_load_inst"], "vmem_note": mix["vmem_note"]}, indent=1))
+    "avg_issue_cycles_per_inst_architectural": round(arch, 3),
+    "avg_issue_cycles_per_inst_single_class_loops": round(loops, 3),
+    "vmem_cycles_per_load_inst": old["vmem_cycles_per_load_inst"], "vmem_note": old["vmem_note"],
+    "counter_note": "SQ_ACTIVE_INST_VALU = 1 per instruction (2 per transcendental) whatever its issue time (profiles/r3_valu_calibration.json): not a busy-cycle count",
+}
+if pmc:
+    measured = pmc["valu_insts_per_ray"] / counts["wave_trips_per_ray"]
+    out.update({"executed_valu_per_wave_trip_measured": round(measured, 1), "model_over_measured": round(total / measured, 4),
+                "measured_from": "profiles/r5_pmc_bench.json: SQ_INSTS_VALU per ray %.2f / wave-trips per ray %.5f (the counting variant's trips; the product's own scheduling "
+                                 "may differ by a fraction of a percent)" % (pmc["valu_insts_per_ray"], counts["wave_trips_per_ray"]),
+                "pmc_source_hash": pmc.get("source_hash")})
+print(json.dumps(out, indent=1))
