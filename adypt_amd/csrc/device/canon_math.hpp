@@ -37,6 +37,15 @@ __device__ __forceinline__ V2 pk_fma_hi(V2 a, V2 b, V2 c)
 	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
 	return r;
 }
+// byte J of x, moved to bits 23 .. 30: the biased exponent byte of a CWBVH8 node as a float's exponent field (= 2^(e - 127)), one SDWA shift
+template <int J> __device__ __forceinline__ float exp_byte(uint32_t x)
+{
+	uint32_t r;
+	if(J == 0) asm("v_lshlrev_b32_sdwa %0, 23, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x));
+	else if(J == 1) asm("v_lshlrev_b32_sdwa %0, 23, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x));
+	else asm("v_lshlrev_b32_sdwa %0, 23, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x));
+	return __uint_as_float(r);
+}
 // (x byte J) << (s byte J) for two words of four packed bytes, one SDWA instruction (the shift uses the low 5 bits of the selected byte)
 template <int J> __device__ __forceinline__ uint32_t shl_bytes(uint32_t s, uint32_t x)
 {

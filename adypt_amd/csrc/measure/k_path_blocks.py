@@ -4,16 +4,21 @@ block itself: it runs exactly when the block's vector instructions are issued, w
 instruction counts between the marks (no GPU needed); tools/path_block_counts.py reads the entry counts on the GPU box; together they are the EXECUTED
 vector instructions per trip (profiles/r5_trip_budget.json, r5_k_path_block_counts.json), which tools/valu_issue_model.py checks against SQ_INSTS_VALU.
     tools/build_variant.sh blocks --transform adypt_amd/csrc/measure/k_path_blocks.py
-Blocks: loop (every iteration) | setup | exchange | shade | trip, and inside the trip: A_pop (A_pop_lds / A_pop_spill) A_choose A_push (A_push_lds is the
-block's remainder / A_push_spill) B_tri_load B_node_load C_woop D_slab E_flush.  What of the trip lies outside every block runs with every trip."""
+Three counting passes (twelve counters each: ADYPT_BLOCKS_SET = trip | shade | rare); every mark is inserted in every pass.  Blocks: setup | exchange | shade | trip;
+inside the trip A_pop (A_pop_spill) A_choose A_push (A_push_spill) B_tri_load B_node_load C_woop D_slab E_flush; inside a shading round S_parked S_miss S_surface
+(S_textured S_glossy S_diffuse S_mirror S_dielectric) S_dead S_alive S_replace S_early S_fetch_more; anywhere div_slow (the division sequence behind rcp_ieee's
+range test) and X_lock_spin.  What lies inside a block but outside its sub-blocks runs whenever the block does."""
 import sys
 d = sys.argv[1]
 import os
 COUNT = os.environ.get("ADYPT_BLOCKS_COUNT", "0") != "0"   # 0: marks only (static counts: tools/trip_budget.py); 1: marks + entry counters (tools/path_block_counts.py)
-SET = os.environ.get("ADYPT_BLOCKS_SET", "trip")           # trip: the blocks of the trip (default) | shade: the blocks inside a shading round (a second counting pass:
-                                                            # there are twelve counters)
-NAMES = ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_push", "B_tri_load", "B_node_load", "C_woop", "D_slab", "E_flush"] if SET == "trip" else \
-        ["shade", "S_parked", "S_miss", "S_surface", "S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric", "S_dead", "S_alive", "S_replace"]
+SET = os.environ.get("ADYPT_BLOCKS_SET", "trip")           # which twelve blocks get the counters (every mark is always inserted): trip | shade | rare
+SETS = {"trip": ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_push", "B_tri_load", "B_node_load", "C_woop", "D_slab", "E_flush"],
+        "shade": ["shade", "S_parked", "S_miss", "S_surface", "S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric", "S_dead", "S_alive", "S_replace"],
+        # blocks expected to run (almost) never: stack entries beyond the LDS part, the division sequence behind rcp_ieee's range test (every site one
+        # counter), the shading round's second and later reservations of replacement paths, its early reservation, the lock's spin
+        "rare": ["trip", "shade", "A_pop_spill", "A_push_spill", "div_slow", "S_fetch_more", "S_early", "X_lock_spin", "exchange", "setup"]}
+NAMES = SETS[SET]
 # Counters: a value that is modified inside a divergent block cannot live in an SGPR the compiler allocates (the merge after the block is per lane).
 # So k_path is held to 96 SGPRs (amdgpu_num_sgpr) and the counters live in s96 .. s101, touched only by inline assembly: two 16-bit counters per
 # register (a wave makes < 65536 trips per launch at the batch sizes measured).
@@ -65,8 +70,8 @@ TRIP_EDITS = [
     ("				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert", "				" + enter("E_flush") + "\n				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert"),
     ("				active = false;\n			}\n		}", "				active = false;\n				" + leave("E_flush") + "\n			}\n		}"),
 ]
-if SET == "trip":
-    edit("traverse_trip.inc", TRIP_EDITS)
+edit("traverse_trip.inc", TRIP_EDITS)
+edit("canon_math.hpp", [("	return 1.0f / x;\n}", "	" + enter("div_slow") + "\n	const float q_slow = 1.0f / x;\n	" + leave("div_slow") + "\n	return q_slow;\n}")])
 # (k_trace includes the trip too: it gets a dummy counter array)
 zero = " ".join('asm volatile("s_mov_b32 s%d, 0" ::: "s%d");' % (r, r) for r in range(96, 102))
 read = " ".join('asm volatile("s_mov_b32 %%0, s%d" : "=s"(bc[%d]));' % (96 + i, i) for i in range(6))
@@ -95,13 +100,20 @@ SHADE_HPP = [
     ("		else if(illum == 6 || illum == 7)\n		{\n			float eta = ior;", "		else if(illum == 6 || illum == 7)\n		{\n			" + enter("S_dielectric") + "\n			float eta = ior;"),
     ("			else dir = reflect3(dir, normal);\n		}\n	}\n	if(b + 1 >= f.max_bounce) alive = false; // last loop iteration", "			else dir = reflect3(dir, normal);\n			" + leave("S_dielectric") + "\n		}\n	}\n	if(b + 1 >= f.max_bounce) alive = false; // last loop iteration"),
 ]
-if SET == "shade":
-    edit("shade.hpp", SHADE_HPP)
-pairs = (SHADE_PATH if SET == "shade" else []) + [
+edit("shade.hpp", SHADE_HPP)
+pairs = SHADE_PATH + [
+    ("					if(early && lane == 0) rel = atomicAdd(&a.cursor[home * kCursorStride], n_sure);", "					if(early && lane == 0) { " + enter("S_early") + " rel = atomicAdd(&a.cursor[home * kCursorStride], n_sure); " + leave("S_early") + " }"),
+    ("						while(served < n_dead) // (wave-uniform) the rest: paths that ended unexpectedly, or the home segment has run out\n						{", "						while(served < n_dead) // (wave-uniform) the rest: paths that ended unexpectedly, or the home segment has run out\n						{\n							" + enter("S_fetch_more")),
+    ("							served += gn;\n						}", "							served += gn;\n							" + leave("S_fetch_more") + "\n						}"),
+    ("			expect = 0u;\n			__builtin_amdgcn_s_sleep(1);", "			" + enter("X_lock_spin") + "\n			expect = 0u;\n			__builtin_amdgcn_s_sleep(1);\n			" + leave("X_lock_spin")),
     ('				asm volatile("; ADYPT_MARK exchange_begin");', "				" + enter("exchange")),
     ('					asm volatile("; ADYPT_MARK shade_begin");', "					" + enter("shade")),
     ('			asm volatile("; ADYPT_MARK setup_begin");', "			" + enter("setup")),
-] + ([("		if(!skip_trip)\n#include \"traverse_trip.inc\"", "		if(!skip_trip)\n		{\n		" + enter("trip") + "\n#include \"traverse_trip.inc\"\n		" + leave("trip") + "\n		}")] if SET == "trip" else [])
+    ("		if(!skip_trip)\n#include \"traverse_trip.inc\"", "		if(!skip_trip)\n		{\n		" + enter("trip") + "\n#include \"traverse_trip.inc\"\n		" + leave("trip") + "\n		}"),
+    ('			asm volatile("; ADYPT_MARK setup_end");', "			" + leave("setup")),
+    ('					asm volatile("; ADYPT_MARK shade_end");', "					" + leave("shade")),
+    ('				asm volatile("; ADYPT_MARK exchange_end");', "				" + leave("exchange")),
+]
 if COUNT:
     pairs += [
         ("template <bool STATS>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathKernArgs K)\n{",

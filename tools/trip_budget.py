@@ -2,7 +2,7 @@
 (VERDICT r4 task 3).  No GPU needed: the device sources are copied, marked by adypt_amd/csrc/measure/k_path_blocks.py (assembly comments only),
 compiled to gfx950 assembly with the Makefile's flags, and the VALU instructions between the marks are counted.
   sections of the trip (traverse_trip.inc): A choose / pop / push, B loads + triangle hand-over, C Woop test + hit update, D slab test, E finished?
-  blocks: the parts behind a wave-level branch (skipped when no lane needs them); `always` = what every trip issues.
+  blocks: the parts behind a wave-level branch (skipped when no lane needs them), nested as in the source; `trip/X` = what every trip issues in section X.
 The product library has no marks inside the trip; its own totals are printed beside the marked build's (they differ by a few instructions: the marks
 are scheduling barriers).  Dynamic weights (how often a block runs) come from tools/path_block_counts.py on the GPU box.
     python tools/trip_budget.py > profiles/r5_trip_budget.json"""
@@ -62,82 +62,70 @@ def count(lines):
     return {"valu": sum(ops.values()), "by_class": dict(cls), "by_opcode": dict(sorted(ops.items(), key=lambda kv: -kv[1]))}
 
 
-def marked_build(flags, block_set):
+def marked_build(flags):
     with tempfile.TemporaryDirectory() as t:
         # (a sibling directory two levels below: the sources include ../../../include/adypt_hip.h)
         dev = os.path.join(t, "a", "b", "device")
         os.makedirs(os.path.dirname(dev))
         shutil.copytree(os.path.join(CSRC, "device"), dev)
         shutil.copytree(os.path.join(ROOT, "include"), os.path.join(t, "include"))
-        subprocess.check_call([sys.executable, os.path.join(CSRC, "measure", "k_path_blocks.py"), dev], env=dict(os.environ, ADYPT_BLOCKS_COUNT="0", ADYPT_BLOCKS_SET=block_set))
+        subprocess.check_call([sys.executable, os.path.join(CSRC, "measure", "k_path_blocks.py"), dev], env=dict(os.environ, ADYPT_BLOCKS_COUNT="0"))
         out = os.path.join(t, "marked.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DADYPT_BUILD", "--cuda-device-only", "-S", os.path.join(dev, "tracer.hip"), "-o", out], stderr=subprocess.DEVNULL)
         return body_of(open(out).read())
 
 
-def shade_blocks(flags):
-    """the blocks INSIDE a shading round (second marked build): what runs every round, and what only when some lane needs it"""
-    lines = marked_build(flags, "shade")
-    marks = {}
-    for i, l in enumerate(lines):
-        m = re.search(r"ADYPT_MARK (\w+)", l)
-        if m:
-            marks.setdefault(m.group(1), i)
-    names = ["S_parked", "S_miss", "S_surface", "S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric", "S_dead", "S_alive", "S_replace"]
-    span = {b: (marks[b + "_begin"], marks[b + "_end"]) for b in names}
-    inner = ["S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric"]  # nested in S_surface
-    per = {b: [] for b in names}
-    every = []
-    for i in range(marks["shade_begin"], marks["shade_end"]):
-        owner = next((b for b in inner if span[b][0] <= i < span[b][1]), None) or next((b for b in names if b not in inner and span[b][0] <= i < span[b][1]), None)
-        (per[owner] if owner else every).append(lines[i])
-    out = {"every round": count(every)}
-    out.update({b: count(per[b]) for b in names})
-    out["valu_static"] = sum(v["valu"] for v in out.values())
-    return out
-
-
 def main():
     flags = hipflags()
-    marked = marked_build(flags, "trip")
+    marked = marked_build(flags)
     subprocess.check_call(["make", "-s", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     product = body_of(open(os.path.join(CSRC, "build", "tracer.s")).read())
 
-    marks = {}
+    first = {}
     for i, l in enumerate(marked):
         m = re.search(r"ADYPT_MARK (\w+)", l)
         if m:
-            marks.setdefault(m.group(1), i)
-    lo, hi = loop_bounds(marked, marks["exchange_end"])
-    trip_lo, trip_hi = marks["trip_begin"], marks["trip_end"]
-    blocks = ["A_pop", "A_choose", "A_push", "B_tri_load", "B_node_load", "C_woop", "D_slab", "E_flush"]
-    span = {b: (marks[b + "_begin"], marks[b + "_end"]) for b in blocks}
-    sec_at = sorted((marks["sec_" + s], s) for s in "ABCDE")
-
-    def section_of(i):
-        cur = "A"
-        for pos, s in sec_at:
-            if i >= pos:
-                cur = s
-        return cur
-
-    in_block = lambda i: next((b for b, (a, e) in span.items() if a <= i < e), None)
-    always = {s: [] for s in "ABCDE"}
-    per_block = {b: [] for b in blocks}
-    for i in range(trip_lo, trip_hi):
-        b = in_block(i)
-        (per_block[b] if b else always[section_of(i)]).append(marked[i])
-    sections = {}
-    for s in "ABCDE":
-        bl = {b: count(per_block[b]) for b in blocks if b.startswith(s + "_")}
-        sections[s] = {"always": count(always[s]), "blocks": bl, "valu_static": count(always[s])["valu"] + sum(v["valu"] for v in bl.values())}
-    regions = {"ray setup": count(marked[marks["setup_begin"]:marks["setup_end"]]),
-               "exchange (in front of a shading round)": count(marked[marks["exchange_begin"]:marks["shade_begin"]]),
-               "shading round": count(marked[marks["shade_begin"]:marks["shade_end"]]),
-               "exchange (after a shading round / without one)": count(marked[marks["shade_end"]:marks["exchange_end"]])}
-    marked_regions = [(marks["setup_begin"], marks["setup_end"]), (marks["exchange_begin"], marks["exchange_end"]), (trip_lo, trip_hi)]
-    rest = [marked[i] for i in range(lo, hi + 1) if not any(a <= i < e for a, e in marked_regions)]
-    # the product build: the trip = from the exchange's end to the loop's last back edge (no marks inside)
+            first.setdefault(m.group(1), i)
+    lo, hi = loop_bounds(marked, first["exchange_end"])
+    # Every vector instruction of the function goes to the innermost open block at its place in the assembly (marks nest like the source's blocks; a block
+    # the compiler moved out of line — the unlikely side of a branch — still carries its own pair of marks).  Outside every block: the loop's own control
+    # when inside the persistent loop, prologue / epilogue otherwise.
+    stack, owner_lines, parents = [], collections.defaultdict(list), {}
+    sec = None
+    for i, l in enumerate(marked):
+        m = re.search(r"ADYPT_MARK (\w+)", l)
+        if m:
+            name = m.group(1)
+            if name.startswith("sec_"):
+                sec = name[4:]
+            elif name.endswith("_begin"):
+                b = name[:-6]
+                parents.setdefault(b, stack[-1] if stack else None)
+                stack.append(b)
+                if b == "trip":
+                    sec = "A"
+            elif name.endswith("_end"):
+                b = name[:-4]
+                if b in stack:
+                    while stack and stack.pop() != b:
+                        pass
+                if b == "trip":
+                    sec = None
+            continue
+        if not is_valu(l):
+            continue
+        if stack:
+            owner = stack[-1] if stack[-1] != "trip" else "trip/" + (sec or "A")
+        else:
+            owner = "loop control" if lo <= i <= hi else "outside the loop"
+        owner_lines[owner].append(l)
+    blocks = {}
+    for owner, ls in owner_lines.items():
+        c = count(ls)
+        base = owner.split("/")[0]
+        c["parent"] = "trip" if owner.startswith("trip/") else parents.get(base)
+        blocks[owner] = c
+    trip_total = sum(c["valu"] for o, c in blocks.items() if o.startswith("trip/") or o[:2] in ("A_", "B_", "C_", "D_", "E_"))
     pm = {}
     for i, l in enumerate(product):
         m = re.search(r"ADYPT_MARK (\w+)", l)
@@ -146,13 +134,14 @@ def main():
     plo, phi = loop_bounds(product, pm["exchange_end"])
     print(json.dumps({
         "kernel": "k_path<false>", "what": __doc__.split("\n    python")[0], "flags": " ".join(flags),
-        "trip_sections": sections,
-        "trip_valu_static_marked_build": sum(v["valu_static"] for v in sections.values()),
+        "blocks": dict(sorted(blocks.items())),
+        "trip_valu_static_marked_build": trip_total,
         "trip_valu_static_product_build": count(product[pm["exchange_end"]:phi + 1])["valu"],
-        "loop_outside_trip": dict(regions, **{"loop control outside every mark (votes, the exchange's condition)": count(rest)}),
-        "shading_round_blocks": shade_blocks(flags),
-        "note": "valu = static count of vector-ALU instructions (v_readlane / v_writelane / v_readfirstlane excluded, as in SQ_INSTS_VALU's complement of scalar work they "
-                "are few).  by_class: full = 2-cycle fp32 / logic / move, normal = 4-cycle, packed64 = v_pk_* and 64-bit (4), trans = 8 (profiles/r3_valu_calibration.json)."}, indent=1))
+        "note": "blocks[name].valu = static count of vector-ALU instructions whose innermost enclosing block is `name` (v_readlane / v_writelane / v_readfirstlane "
+                "excluded); 'trip/A' .. 'trip/E' = what every trip issues, by section of traverse_trip.inc (A choose / pop / push, B loads + triangle hand-over, "
+                "C Woop test + hit update, D slab test, E finished?); parent = the block it sits in.  by_class: full = 2-cycle fp32 / logic / move, normal = 4-cycle, "
+                "packed64 = v_pk_* and 64-bit (4), trans = 8 (profiles/r3_valu_calibration.json).  The product build's trip (no marks inside) is counted from the "
+                "exchange's end to the loop's last back edge, rare out-of-line blocks included."}, indent=1))
 
 
 if __name__ == "__main__":

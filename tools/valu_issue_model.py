@@ -1,7 +1,8 @@
 """Build profiles/r5_valu_issue_model.json (read by bench.py): the vector-ALU issue model of k_path<false>, weighted by EXECUTED instructions.
 
   static counts   profiles/r5_trip_budget.json      tools/trip_budget.py: vector instructions per block of the persistent loop, by issue class (no GPU)
-  block entries   profiles/r5_k_path_block_counts.json   tools/path_block_counts.py: how often a wave enters each block (counting variant, GPU)
+  block entries   profiles/r5_k_path_block_counts.json, r5_k_path_shade_block_counts.json, r5_k_path_rare_block_counts.json
+                                                     tools/path_block_counts.py: how often a wave enters each block (three counting variants, GPU)
   issue cycles    profiles/r3_valu_calibration.json  one-instruction loops: TRUE cycles a wave-instruction holds its SIMD's issue, per class
   check           profiles/r5_pmc_bench.json         SQ_INSTS_VALU per ray of the product kernel (rocprofv3 --pmc, tools/collect_profiles.sh)
 
@@ -27,24 +28,36 @@ CLASSES = [
     ("packed64", "packed fp32 (v_pk_fma_f32) / 64-bit", 4, ["k_pk_fma", "k_mad_u64"]),
     ("trans", "transcendental (v_rcp_f32, v_sqrt_f32)", 8, ["k_rcp", "k_sqrt"]),
 ]
+# entries per trip of every counted block: the trip set directly; the shade and rare sets (other launches of the same frames) through their own `shade` / `trip` counts
 entries = counts["wave_entries"]
 trips = float(entries["trip"])
-w = {k: v / trips for k, v in entries.items()}  # entries per trip
+w = {k: v / trips for k, v in entries.items()}
+for name in ("r5_k_path_shade_block_counts.json", "r5_k_path_rare_block_counts.json"):
+    if not os.path.exists(P(name)):
+        continue
+    e = json.load(open(P(name)))["wave_entries"]
+    scale = (1.0 / e["trip"]) if "trip" in e else (w["shade"] / e["shade"])
+    for k, v in e.items():
+        w.setdefault(k, v * scale)
 
-blocks = []  # (name, weight = executions per trip, static count object)
-for sec, body in budget["trip_sections"].items():
-    blocks.append(("trip %s: every trip" % sec, 1.0, body["always"]))
-    for b, c in body["blocks"].items():
-        blocks.append(("trip %s: %s" % (sec, b), w[b], c))
-lo = budget["loop_outside_trip"]
-blocks.append(("ray setup", w["setup"], lo["ray setup"]))
-blocks.append(("exchange", w["exchange"], lo["exchange (in front of a shading round)"]))
-blocks.append(("exchange, after the round", w["exchange"], lo["exchange (after a shading round / without one)"]))
-blocks.append(("shading round", w["shade"], lo["shading round"]))
-# loop control (votes, the exchange's condition): once per iteration = per trip + per iteration that skips the trip (a setup follows an exchange)
-rest_key = [k for k in lo if k.startswith("loop control")][0]
-blocks.append(("loop control", 1.0 + w["setup"], lo[rest_key]))
+B = budget["blocks"]
 
+
+def weight(owner):
+    """executions per trip of the block that owns an instruction: its own counter, else the block it sits in"""
+    if owner.startswith("trip/"):
+        return 1.0
+    if owner == "loop control":
+        return 1.0 + w["setup"]  # once per iteration: per trip, and per iteration that starts rays instead (a setup follows an exchange)
+    if owner == "outside the loop":
+        return 0.0
+    if owner in w:
+        return w[owner]
+    parent = B[owner].get("parent")
+    return weight(parent) if parent else 1.0
+
+
+blocks = [(owner, weight(owner), c) for owner, c in B.items() if owner != "outside the loop"]
 per_class = {c[0]: 0.0 for c in CLASSES}
 rows, total = [], 0.0
 for name, weight, c in blocks:
