@@ -7,7 +7,7 @@ vector instructions per trip (profiles/r5_trip_budget.json, r5_k_path_block_coun
 Three counting passes (twelve counters each: ADYPT_BLOCKS_SET = trip | shade | rare); every mark is inserted in every pass.  Blocks: setup | exchange | shade | trip;
 inside the trip A_pop (A_pop_spill) A_choose A_push (A_push_spill) B_tri_load B_node_load C_woop D_slab E_flush; inside a shading round S_parked S_miss S_surface
 (S_textured S_glossy S_diffuse S_mirror S_dielectric) S_dead S_alive S_replace S_early S_fetch_more; anywhere div_slow (the division sequence behind rcp_ieee's
-range test) and X_lock_spin.  What lies inside a block but outside its sub-blocks runs whenever the block does."""
+range test), F_try (one try of fetch_rays at one queue segment) and X_lock_spin.  What lies inside a block but outside its sub-blocks runs whenever the block does."""
 import sys
 d = sys.argv[1]
 import os
@@ -17,7 +17,7 @@ SETS = {"trip": ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_p
         "shade": ["shade", "S_parked", "S_miss", "S_surface", "S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric", "S_dead", "S_alive", "S_replace"],
         # blocks expected to run (almost) never: stack entries beyond the LDS part, the division sequence behind rcp_ieee's range test (every site one
         # counter), the shading round's second and later reservations of replacement paths, its early reservation, the lock's spin
-        "rare": ["trip", "shade", "A_pop_spill", "A_push_spill", "div_slow", "S_fetch_more", "S_early", "X_lock_spin", "exchange", "setup"]}
+        "rare": ["trip", "shade", "A_pop_spill", "A_push_spill", "div_slow", "S_fetch_more", "S_early", "X_lock_spin", "exchange", "setup", "F_try"]}
 NAMES = SETS[SET]
 # Counters: a value that is modified inside a divergent block cannot live in an SGPR the compiler allocates (the merge after the block is per lane).
 # So k_path is held to 96 SGPRs (amdgpu_num_sgpr) and the counters live in s96 .. s101, touched only by inline assembly: two 16-bit counters per
@@ -71,6 +71,10 @@ TRIP_EDITS = [
     ("				active = false;\n			}\n		}", "				active = false;\n				" + leave("E_flush") + "\n			}\n		}"),
 ]
 edit("traverse_trip.inc", TRIP_EDITS)
+# (fetch_rays' loop over the 8 queue segments is unrolled: 8 equal instances of the block, one counter = tries in all)
+edit("traverse.hpp", [("		if((seg_done >> s) & 1u) continue;\n		const uint32_t seg_len = (uint32_t)__builtin_amdgcn_readlane((int)seg_len_lanes, s);",
+                       "		if((seg_done >> s) & 1u) continue;\n		" + enter("F_try") + "\n		const uint32_t seg_len = (uint32_t)__builtin_amdgcn_readlane((int)seg_len_lanes, s);"),
+                      ("		seg_done |= 1u << s;\n	}\n	*left = 0;", "		seg_done |= 1u << s;\n		" + leave("F_try") + "\n	}\n	*left = 0;")])
 edit("canon_math.hpp", [("	return 1.0f / x;\n}", "	" + enter("div_slow") + "\n	const float q_slow = 1.0f / x;\n	" + leave("div_slow") + "\n	return q_slow;\n}")])
 # (k_trace includes the trip too: it gets a dummy counter array)
 zero = " ".join('asm volatile("s_mov_b32 s%d, 0" ::: "s%d");' % (r, r) for r in range(96, 102))

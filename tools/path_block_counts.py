@@ -4,14 +4,17 @@ workload.  Needs the counting variant:
     ADYPT_LIB=adypt_amd/libadypt_blockcnt.so python tools/path_block_counts.py > profiles/r5_k_path_block_counts.json
     ADYPT_BLOCKS_COUNT=1 ADYPT_BLOCKS_SET=shade tools/build_variant.sh shadecnt --transform adypt_amd/csrc/measure/k_path_blocks.py
     ADYPT_BLOCKS_SET=shade ADYPT_LIB=adypt_amd/libadypt_shadecnt.so python tools/path_block_counts.py > profiles/r5_k_path_shade_block_counts.json
+    (and the same with `rare` / rarecnt -> profiles/r5_k_path_rare_block_counts.json)
 With tools/trip_budget.py's static counts these are the EXECUTED vector instructions per trip, which tools/valu_issue_model.py checks against SQ_INSTS_VALU."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from adypt_amd import api, scenes, _native as N
-SET = os.environ.get("ADYPT_BLOCKS_SET", "trip")  # which counting variant ADYPT_LIB is: the trip's blocks, or (a second pass) the blocks inside a shading round
-NAMES = ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_push", "B_tri_load", "B_node_load", "C_woop", "D_slab", "E_flush"] if SET == "trip" else \
-        ["shade", "S_parked", "S_miss", "S_surface", "S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric", "S_dead", "S_alive", "S_replace"]
+SET = os.environ.get("ADYPT_BLOCKS_SET", "trip")  # which counting variant ADYPT_LIB is: trip | shade | rare
+SETS = {"trip": ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_push", "B_tri_load", "B_node_load", "C_woop", "D_slab", "E_flush"],
+        "shade": ["shade", "S_parked", "S_miss", "S_surface", "S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric", "S_dead", "S_alive", "S_replace"],
+        "rare": ["trip", "shade", "A_pop_spill", "A_push_spill", "div_slow", "S_fetch_more", "S_early", "X_lock_spin", "exchange", "setup", "F_try"]}  # = adypt_amd/csrc/measure/k_path_blocks.py
+NAMES = SETS[SET]
 scene = os.environ.get("SWEEP_SCENE", "sponza"); fr = int(os.environ.get("SWEEP_FRAMES", "20")); warm = int(os.environ.get("SWEEP_WARMUP", "5"))
 spec = scenes.make_scene(scene, os.environ.get("ADYPT_CACHE", "/tmp/adypt_cache"), width=1920, height=1080,
                          pt={"maxBounce": 8, "tmpLifetime": 16, "stackSize": 24, "subpixel": 8, "clamp": 4.0, "sun": [12.0, 11.0, 10.0]})

@@ -90,7 +90,7 @@ def main():
     # Every vector instruction of the function goes to the innermost open block at its place in the assembly (marks nest like the source's blocks; a block
     # the compiler moved out of line — the unlikely side of a branch — still carries its own pair of marks).  Outside every block: the loop's own control
     # when inside the persistent loop, prologue / epilogue otherwise.
-    stack, owner_lines, parents = [], collections.defaultdict(list), {}
+    stack, owner_lines, parents, instances = [], collections.defaultdict(list), {}, collections.Counter()
     sec = None
     for i, l in enumerate(marked):
         m = re.search(r"ADYPT_MARK (\w+)", l)
@@ -101,6 +101,7 @@ def main():
             elif name.endswith("_begin"):
                 b = name[:-6]
                 parents.setdefault(b, stack[-1] if stack else None)
+                instances[b] += 1
                 stack.append(b)
                 if b == "trip":
                     sec = "A"
@@ -124,6 +125,7 @@ def main():
         c = count(ls)
         base = owner.split("/")[0]
         c["parent"] = "trip" if owner.startswith("trip/") else parents.get(base)
+        c["instances"] = instances.get(base, 1)  # > 1: an inlined / unrolled block; its one counter counts the entries of all of them
         blocks[owner] = c
     trip_total = sum(c["valu"] for o, c in blocks.items() if o.startswith("trip/") or o[:2] in ("A_", "B_", "C_", "D_", "E_"))
     pm = {}
@@ -137,7 +139,7 @@ def main():
         "blocks": dict(sorted(blocks.items())),
         "trip_valu_static_marked_build": trip_total,
         "trip_valu_static_product_build": count(product[pm["exchange_end"]:phi + 1])["valu"],
-        "note": "blocks[name].valu = static count of vector-ALU instructions whose innermost enclosing block is `name` (v_readlane / v_writelane / v_readfirstlane "
+        "note": "blocks[name].valu = static count of vector-ALU instructions whose innermost enclosing block is `name` (summed over its `instances`) (v_readlane / v_writelane / v_readfirstlane "
                 "excluded); 'trip/A' .. 'trip/E' = what every trip issues, by section of traverse_trip.inc (A choose / pop / push, B loads + triangle hand-over, "
                 "C Woop test + hit update, D slab test, E finished?); parent = the block it sits in.  by_class: full = 2-cycle fp32 / logic / move, normal = 4-cycle, "
                 "packed64 = v_pk_* and 64-bit (4), trans = 8 (profiles/r3_valu_calibration.json).  The product build's trip (no marks inside) is counted from the "

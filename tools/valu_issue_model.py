@@ -52,7 +52,7 @@ def weight(owner):
     if owner == "outside the loop":
         return 0.0
     if owner in w:
-        return w[owner]
+        return w[owner] / B[owner].get("instances", 1)  # (equal-sized instances of one inlined block share a counter: static sum x entries / instances)
     parent = B[owner].get("parent")
     return weight(parent) if parent else 1.0
 
