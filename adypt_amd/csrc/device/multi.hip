@@ -308,7 +308,7 @@ int adypt_create_multi(adypt_multi **out, const adypt_scene_desc *desc, const in
 	adypt_multi *m = new adypt_multi();
 	m->shared_device = shared;
 	m->tun = tun;
-	// One host thread per device: each context is an upload of the whole scene (80 MB .. 2.7 GB) plus its own allocations, and the devices
+	// One host thread per device: each context is an upload of the whole scene (80 MB .. 1.9 GB) plus its own allocations, and the devices
 	// do not share a PCIe link — created one after the other, an 8-GPU start-up took 8 x the 1-GPU time.  (Several shards on ONE device, the
 	// test hook, are created in turn: they would only queue up behind each other on the device's legacy stream.)
 	std::vector<adypt_ctx *> made((size_t)n_dev, nullptr);

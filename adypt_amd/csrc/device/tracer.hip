@@ -33,6 +33,7 @@ constexpr int kMaxBounce = 32;
 constexpr int kMaxFramesInFlight = 128;
 constexpr int kMaxPipes = 4;           // sub-batches of a batch that run as concurrent chains (adypt_set_pipeline)
 constexpr long kRefTrianglesAutoMaxMB = 1l << 20; // ADYPT_REF_TRIANGLES_MAX_MB unset: the per-reference triangle copy is made whatever its size
+constexpr int kRollMaxPixels = 1 << 22;   // single frames in a row overlap on two streams up to this many local pixels (trace_rolling_frame)
 constexpr int kDefaultPipes = 1;       // measured: a second chain overlaps but recovers nothing (profiles/r3_ablations_k_trace.txt)
 
 struct FrameCounters {                 // one memset per frame; every counter on its own 128-byte line
@@ -836,7 +837,9 @@ int trace_rolling_frame(adypt_ctx *c, const SceneArgs &sc, const PixelArgs &px, 
 	// image 1 stays what frame-by-frame tracing leaves there): enqueued NOW, behind frame `frame`'s k_path — it fills the compute units as that launch's
 	// workgroups end.  Its slot's previous frame (frame - 1) had its running-mean step enqueued by the previous call of this function.
 	const int life = std::max(1, c->params.tmp_lifetime);
-	const bool ahead = c->single_overlap && (more || (c->lookahead && (frame + 1) % life != 0));
+	// (only while a frame is small enough for the end of its launch to matter: at 4096 x 4096 — 99 M rays, 14 ms per frame — the next frame's bounce 0
+	// running beside the current k_path costs 3 % where the launch's end is worth 3 %: measured 6566 against 6777 Mrays/s, profiles/r5_ablations.txt)
+	const bool ahead = c->single_overlap && c->n_local_px <= kRollMaxPixels && (more || (c->lookahead && (frame + 1) % life != 0));
 	if(ahead && c->roll_frame[s ^ 1] != frame + 1)
 	{
 		if(c->roll_frame[s ^ 1] >= 0) drop_rolling(c);

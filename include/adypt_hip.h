@@ -176,7 +176,7 @@ int adypt_set_lookahead(adypt_ctx *ctx, int enabled);
  * keeps the launch-per-bounce frame) — unless the sun-visibility query or the sub-batch pipeline is on or the batch has more than 2^26 paths.
  * Images are bit-identical either way.  The getter says whether the LAST batch used it.
  * Memory: k_path looks a hit's triangle up by REFERENCE index in a second copy of the 128-byte triangle records (n_refs x 128 B: 43 MB for the
- * 249 k-triangle bench scene), allocated at adypt_create (2.1 GB at 10 M triangles; measured +3 % there and +1 % on the bench scene against the remap, so no size limit
+ * 249 k-triangle bench scene), allocated at adypt_create (1.3 GB for the 10.1 M references of the 10 M-triangle stand-in; measured +3 % there and +1 % on the bench scene against the remap, so no size limit
  * by default: ADYPT_REF_TRIANGLES_MAX_MB sets one); above the limit, or when the allocation fails, k_path goes through the 4-byte uTriIndices
  * remap instead — same image. */
 int adypt_set_fused_bounces(adypt_ctx *ctx, int enabled);

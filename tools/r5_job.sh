@@ -1,5 +1,6 @@
 set -u
 export TMPDIR=/tmp ADYPT_CACHE=/tmp/adypt_cache
-mkdir -p gpurun_out/r5
-ADYPT_BLOCKS_SET=rare ADYPT_LIB=$PWD/adypt_amd/libadypt_rarecnt.so timeout -k 10 300 python tools/path_block_counts.py > gpurun_out/r5/rare_block_counts.json 2> gpurun_out/r5/rare_block_counts.err; echo "rarecnt rc $?"; cat gpurun_out/r5/rare_block_counts.json
-timeout -k 10 1000 bash tools/collect_profiles.sh sanmiguel > gpurun_out/r5/collect_sanmiguel.log 2>&1; echo "collect sanmiguel rc $?"; grep -E "valu_insts_per_ray|traffic_bytes_per_ray\"|source_hash|effective_clock|utcl1|fabric_read|l1_to_l2|TCC_hit" gpurun_out/profiles_sanmiguel/pmc_profile.json
+O=gpurun_out/r5/final; mkdir -p $O
+for n in 1 2 4 8; do SWEEP_NRANKS=$n timeout -k 10 300 python tools/path_sweep.py 1 "-:" "-:ADYPT_FUSED_BOUNCES=0"; done > $O/shard.log 2> $O/shard.err; echo "shard rc $?"
+timeout -k 10 300 python tools/primary_rate.py 200 > $O/primary.log 2>&1; echo "primary rc $?"
+timeout -k 10 600 python tools/shard_breakdown.py > $O/shard_breakdown.log 2> $O/shard_breakdown.err; echo "breakdown rc $?"; tail -3 $O/shard_breakdown.log | cut -c1-300
