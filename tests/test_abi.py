@@ -72,3 +72,23 @@ def test_invalid_bvh_is_rejected_before_touching_the_gpu():
     with pytest.raises(N.AdyptError) as e:
         api.HipPathTracer().Initialize(api.InstanceConfig().pt_params(), hs, 64, 36)
     assert e.value.code == N.E_INVALID
+
+
+def test_test_hooks_need_the_magic_and_the_environment_is_read_in_one_place():
+    """adypt_enable_test_hooks refuses anything but ADYPT_TEST_HOOKS_MAGIC, and csrc/device looks at the environment in ONE function (read_tunables):
+    a hook variable cannot reach the library by any other road."""
+    from adypt_amd import _native as N
+    assert N.lib.adypt_enable_test_hooks(0) == N.E_INVALID and N.lib.adypt_enable_test_hooks(0x7465737468303030) == N.E_INVALID
+    magic = int(re.search(r"#define ADYPT_TEST_HOOKS_MAGIC (0x[0-9a-f]+)ull", open(os.path.join(ROOT, "include", "adypt_hip.h")).read()).group(1), 16)
+    from adypt_amd import api
+    assert api.TEST_HOOKS_MAGIC == magic
+    dev = os.path.join(ROOT, "adypt_amd", "csrc", "device")
+    uses = []
+    for f in sorted(os.listdir(dev)):
+        text = open(os.path.join(dev, f)).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        uses += [(f, m.start()) for m in re.finditer(r"\bgetenv\s*\(", text)]
+    assert uses and all(f == "tracer.hip" for f, _ in uses)
+    src = re.sub(r"//[^\n]*", "", open(os.path.join(dev, "tracer.hip")).read())
+    a, b = src.index("Tunables read_tunables()"), src.index("CtxInfo ctx_info(adypt_ctx *c)")
+    assert all(a < pos < b for _, pos in uses), "getenv outside read_tunables()"
