@@ -13,6 +13,7 @@
 #include "host_transport.hpp"
 #include "tunables.hpp"
 #include "../../../include/adypt_hip.h"
+#include "../../../include/adypt_host.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -315,9 +316,18 @@ int adypt_create_multi(adypt_multi **out, const adypt_scene_desc *desc, const in
 	std::vector<int> rc((size_t)n_dev, ADYPT_OK);
 	std::vector<std::string> why((size_t)n_dev);
 	m->setup_s.assign((size_t)n_dev, 0.0);
+	// the Woop matrices (OglScene::init_triangles) are the same for every device: computed once here, not once per context
+	std::vector<float> woop_once;
+	adypt_scene_desc shared_desc = *desc;
+	if(!shared_desc.woop && n_dev > 1 && shared_desc.n_refs > 0 && shared_desc.triangles && shared_desc.tri_indices)
+	{
+		woop_once.resize((size_t)shared_desc.n_refs * 12);
+		adypt_woop_matrices(shared_desc.triangles, shared_desc.tri_indices, shared_desc.n_refs, woop_once.data());
+		shared_desc.woop = woop_once.data();
+	}
 	auto create_one = [&](int i) {
 		const auto t0 = std::chrono::steady_clock::now();
-		adypt_scene_desc d = *desc;
+		adypt_scene_desc d = shared_desc;
 		d.device = device_ids[i]; d.tile_rank = i; d.tile_nranks = n_dev;
 		rc[(size_t)i] = adypt_create(&made[(size_t)i], &d);
 		if(rc[(size_t)i] != ADYPT_OK) why[(size_t)i] = adypt_last_error(nullptr); // (thread-local: read on the thread that failed)
