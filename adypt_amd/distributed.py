@@ -19,6 +19,8 @@ from . import _native as N
 
 BLOCK = 32
 BLOCK_PIXELS = BLOCK * BLOCK
+import time as _time
+_PROCESS_START = _time.time()  # (import time of this module: bench.py imports it before the scene is built)
 
 
 def block_count(width: int, height: int, rank: int, world: int) -> int:
@@ -152,6 +154,10 @@ def exchange_unique_id(rank: int, world: int, path: Optional[str] = None, make_i
         return make_id()
     if rank == 0:
         try:
+            os.unlink(path)  # (a stale id of an earlier job: see below)
+        except OSError:
+            pass
+        try:
             uid = make_id()
         except Exception:
             try:
@@ -172,9 +178,14 @@ def exchange_unique_id(rank: int, world: int, path: Optional[str] = None, make_i
         try:
             fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
             with os.fdopen(fd, "rb") as f:
-                if os.fstat(f.fileno()).st_uid != os.getuid():
+                st = os.fstat(f.fileno())
+                if st.st_uid != os.getuid():
                     raise RuntimeError("rendezvous file %s belongs to another user" % path)
                 uid = f.read()
+            # an id left behind by an EARLIER job that died before rank 0 could remove it (same launcher port, back-to-back runs) must not be taken
+            # for this job's: only a file written after this process started counts (rank 0 writes its id seconds after the ranks start)
+            if st.st_mtime < _PROCESS_START - 5.0:
+                uid = b""
             if len(uid) == 128:
                 return uid
             if uid == b"failed":

@@ -156,3 +156,18 @@ def test_rendezvous_file_lives_in_a_private_directory_and_is_never_followed_thro
         assert target.read_bytes() == b"x" * 128 and not os.path.islink(p)
     finally:
         tempfile.tempdir = None
+
+
+def test_a_stale_id_of_an_earlier_job_is_not_taken_for_this_jobs(tmp_path):
+    """Back-to-back jobs of one launcher port (the driver runs N = 1, 2, 4, 8 in a row): an id file a dead job left behind must be ignored by the
+    waiting ranks until rank 0 of THIS job has written its own."""
+    from adypt_amd import distributed as D
+    path = str(tmp_path / "id")
+    with open(path, "wb") as f:
+        f.write(b"\xee" * 128)
+    old = time.time() - 3600
+    os.utime(path, (old, old))
+    with pytest.raises(TimeoutError):
+        D.exchange_unique_id(1, 2, path=path, timeout_s=0.5)         # the stale id is not returned
+    assert D.exchange_unique_id(0, 2, path=path, make_id=lambda: bytes(range(128))) == bytes(range(128))
+    assert D.exchange_unique_id(1, 2, path=path, timeout_s=5.0) == bytes(range(128))
