@@ -1,6 +1,4 @@
 set -u
 export TMPDIR=/tmp ADYPT_CACHE=/tmp/adypt_cache
-mkdir -p gpurun_out/r5
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r5/gputest.log 2>&1; rc=$?; echo "pytest rc $rc" >> gpurun_out/r5/gputest.log; tail -3 gpurun_out/r5/gputest.log
-[ $rc -eq 0 ] || exit 1
-timeout -k 10 900 bash tools/collect_profiles.sh > gpurun_out/r5/collect_bench.log 2>&1; echo "collect bench rc $?"; grep -E "valu_insts_per_ray|source_hash" gpurun_out/profiles_bench/pmc_profile.json
+O=gpurun_out/r5/final; mkdir -p $O
+timeout -k 10 1000 bash tools/collect_profiles.sh sanmiguel > gpurun_out/r5/collect_sanmiguel.log 2>&1; echo "collect sanmiguel rc $?"; grep -E "valu_insts_per_ray|source_hash|traffic_bytes_per_ray\"" gpurun_out/profiles_sanmiguel/pmc_profile.json
