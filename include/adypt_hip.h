@@ -168,7 +168,13 @@ int adypt_get_pipeline(const adypt_ctx *ctx);
  * the following calls only apply one running-mean step per frame.  The image, adypt_get_spp and image 1 (adypt_read_hits)
  * after every call are bit-identical to frame-by-frame tracing; adypt_get_stats counts work when it is done, i.e. includes
  * frames traced ahead.  adypt_set_camera, adypt_reset, adypt_trace_primary, adypt_set_sun_visibility and
- * adypt_set_frames_in_flight drop the parked frames (they are traced again, with the new state, when asked for). */
+ * adypt_set_frames_in_flight drop the parked frames (they are traced again, with the new state, when asked for).
+ * One frame per wavefront pass (adypt_set_frames_in_flight(ctx, 1), or any call that asks for a single frame with look-ahead off): consecutive single frames
+ * run on two HIP streams — frame k + 1's bounce 0 and k_path are enqueued under the END of frame k's k_path launch (its last paths' sequential bounces, a
+ * quarter of a 1080p frame's time) whenever the call itself asks for frame k + 1; with look-ahead ON also across calls: frame k + 1 is STARTED (not parked:
+ * adypt_get_lookahead_frames stays 0) before the call for frame k returns, unless it would re-trace primary rays (image 1 stays what frame-by-frame tracing
+ * leaves there).  A started frame is waited for and forgotten by the calls listed above and by adypt_trace_rays; images are bit-identical either way
+ * (ADYPT_SINGLE_OVERLAP=0 in the environment: strictly one frame after the other).  Off above 2^22 local pixels, where a launch's end no longer matters. */
 int adypt_set_lookahead(adypt_ctx *ctx, int enabled);
 /* Bounces 1 .. maxBounce-1 of a batch of frames in ONE persistent launch (k_path: the reference's for(b < uMaxBounce) inside one
  * dispatch, shaders/pathtracer.glsl:107, src/Tracer/OglPathTracer.cpp:60) instead of a traversal and a shade launch per bounce.  On by
