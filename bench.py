@@ -289,7 +289,8 @@ def main() -> None:
     ap.add_argument("--no-single-frame", action="store_true")
     ap.add_argument("--no-extra-blocks", action="store_true", help="skip primary_only and tmp_lifetime_1")
     ap.add_argument("--cache", default=os.environ.get("ADYPT_CACHE", os.path.join(ROOT, ".adypt_cache")))
-    ap.add_argument("--selfcheck", action="store_true", help="N > 1: before anything is timed, render 2 frames on the N GPUs and on GPU 0 alone and compare the two images bit for bit; exit 3 on a mismatch")
+    ap.add_argument("--selfcheck", action="store_true", help="N > 1 (the default there): before anything is timed, render 2 frames on the N GPUs and on GPU 0 alone and compare the two images bit for bit; exit 3 on a mismatch")
+    ap.add_argument("--no-selfcheck", action="store_true", help="N > 1: skip that check")
     ap.add_argument("--rehearsal", action="store_true", help="NOT a measurement: enables the library's test hooks (adypt_enable_test_hooks) so that ADYPT_MULTI_SHARED_DEVICE / "
                                                              "ADYPT_COMM_TRANSPORT=host can stand in for N GPUs on a box with one")
     args = ap.parse_args()
@@ -422,7 +423,7 @@ def main() -> None:
 
     # ---- --selfcheck: the assembled N-GPU image against the 1-GPU image of the same frames, before anything is timed ------------
     selfcheck = None
-    if args.selfcheck and (multi or world > 1):
+    if (multi or world > 1) and not args.no_selfcheck:  # (on by default: a scaling line must never describe a wrong image)
         pt.Reset()
         pt.Trace(True, 2)
         img_n = gather()
