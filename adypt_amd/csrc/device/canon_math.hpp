@@ -37,6 +37,10 @@ __device__ __forceinline__ V2 pk_fma_hi(V2 a, V2 b, V2 c)
 	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
 	return r;
 }
+// IEEE maxNum / minNum of two values that are never signalling NaNs (slab distances, tmin, the hit distance): the instruction itself.  Written out
+// because the compiler, not knowing that, first quiets a loop-carried or kernel-argument operand with a v_max_f32 x, x of its own (two per slab test).
+__device__ __forceinline__ float max_num(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float min_num(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // byte J of x, moved to bits 23 .. 30: the biased exponent byte of a CWBVH8 node as a float's exponent field (= 2^(e - 127)), one SDWA shift
 template <int J> __device__ __forceinline__ float exp_byte(uint32_t x)
 {

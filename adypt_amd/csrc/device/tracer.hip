@@ -826,25 +826,24 @@ int roll_launch(adypt_ctx *c, const SceneArgs &sc, const PixelArgs &px, bool sta
 int trace_rolling_frame(adypt_ctx *c, const SceneArgs &sc, const PixelArgs &px, bool stats, bool more)
 {
 	const int frame = c->spp, s = frame & 1;
-	int r;
+	// While frames come in order the slots hold nothing but `frame` (slot s: started ahead by the previous call) and `frame + 1` (slot s ^ 1); anything else
+	// is waited for and forgotten first.
+	if((c->roll_frame[s] >= 0 && c->roll_frame[s] != frame) || (c->roll_frame[s ^ 1] >= 0 && c->roll_frame[s ^ 1] != frame + 1)) drop_rolling(c);
 	if(c->roll_frame[s] != frame)
 	{
-		if(c->roll_frame[s] >= 0) drop_rolling(c); // (a slot that holds some other frame: cannot happen while frames come in order)
-		r = roll_launch(c, sc, px, stats, frame, s);
+		const int r = roll_launch(c, sc, px, stats, frame, s);
 		if(r != ADYPT_OK) { drop_rolling(c); return r; }
 	}
-	// The frame after it, when this call asks for it (or the caller switched look-ahead on and it belongs to the same tmpLifetime group, so that
-	// image 1 stays what frame-by-frame tracing leaves there): enqueued NOW, behind frame `frame`'s k_path — it fills the compute units as that launch's
-	// workgroups end.  Its slot's previous frame (frame - 1) had its running-mean step enqueued by the previous call of this function.
+	// The frame after it, when this call asks for it (or the caller switched look-ahead on and it belongs to the same tmpLifetime group, so that image 1
+	// stays what frame-by-frame tracing leaves there): enqueued NOW, behind frame `frame`'s k_path — it fills the compute units as that launch's workgroups
+	// end.  Its slot's previous frame (frame - 1) had its running-mean step enqueued by the previous call of this function.  Only while a frame is small
+	// enough for the end of its launch to matter: at 4096 x 4096 (99 M rays, 14 ms per frame) the next frame's bounce 0 running beside the current k_path
+	// costs the 3 % the launch's end is worth (6566 against 6777 Mrays/s, profiles/r5_ablations.txt 3).
 	const int life = std::max(1, c->params.tmp_lifetime);
-	// (only while a frame is small enough for the end of its launch to matter: at 4096 x 4096 — 99 M rays, 14 ms per frame — the next frame's bounce 0
-	// running beside the current k_path costs 3 % where the launch's end is worth 3 %: measured 6566 against 6777 Mrays/s, profiles/r5_ablations.txt)
 	const bool ahead = c->single_overlap && c->n_local_px <= kRollMaxPixels && (more || (c->lookahead && (frame + 1) % life != 0));
 	if(ahead && c->roll_frame[s ^ 1] != frame + 1)
 	{
-		if(c->roll_frame[s ^ 1] >= 0) drop_rolling(c);
-		if(c->roll_frame[s] != frame) { r = roll_launch(c, sc, px, stats, frame, s); if(r != ADYPT_OK) { drop_rolling(c); return r; } } // (dropped with the other slot)
-		r = roll_launch(c, sc, px, stats, frame + 1, s ^ 1);
+		const int r = roll_launch(c, sc, px, stats, frame + 1, s ^ 1);
 		if(r != ADYPT_OK) { drop_rolling(c); return r; }
 	}
 	// running mean of frame `frame` (pathtracer.glsl:224-226) once its k_path has ended

@@ -1,6 +1,6 @@
 set -u
 export TMPDIR=/tmp ADYPT_CACHE=/tmp/adypt_cache
-for scene in sponza sanmiguel; do
-  echo "== $scene"
-  SWEEP_SCENE=$scene timeout -k 10 600 python tools/sweep_env.py "" "ADYPT_REFILL_MIN=12" "ADYPT_REFILL_MIN=14" "" "ADYPT_REFILL_MIN=12" "ADYPT_REFILL_MIN=14" "" "ADYPT_REFILL_MIN=12" "ADYPT_REFILL_MIN=14" 2>/dev/null
-done
+mkdir -p gpurun_out/r5
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r5/gputest.log 2>&1; rc=$?; echo "pytest rc $rc" >> gpurun_out/r5/gputest.log; tail -3 gpurun_out/r5/gputest.log
+[ $rc -eq 0 ] || exit 1
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
