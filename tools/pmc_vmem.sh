@@ -21,5 +21,5 @@ for grp in "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE" \
 done
 python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
 find $OUT -name "*counter_collection.csv" -delete
-grep -A40 "^k_trace<false" $OUT/pmc_summary.txt | sed -n 1,45p
+grep -A40 "^k_path<false\|^k_trace<false" $OUT/pmc_summary.txt | sed -n 1,90p
 grep -A30 "^k_shade" $OUT/pmc_summary.txt | sed -n 1,32p
