@@ -12,22 +12,26 @@ The timed region (W untimed warm-up steps, then exactly K steps between barriers
 `value` is the median, the spread is printed beside it.
 
 N > 1: the frame is sharded by 32x32 pixel tile over the GPUs (zero communication while rendering) and the timed region ends with the
-single gather of the fp32 radiance on GPU 0 (RCCL over xGMI, inside the library).  Total work is fixed as N grows -> "scaling": "strong".
+single gather of the fp32 radiance on GPU 0 (RCCL over xGMI, inside the library).  Before anything is timed the assembled N-GPU image of two frames
+is compared bit for bit with the 1-GPU image (exit 3 on a mismatch; --no-selfcheck skips it).  Total work is fixed as N grows -> "scaling": "strong".
 Two ways to get N GPUs, the same tile shard and gather either way:
   * started by a launcher (WORLD_SIZE = N): one process per GPU, adypt_comm_* (ncclCommInitRank);
   * started plainly as `python bench.py --gpus N`: ONE process drives the N devices through adypt_create_multi (ncclCommInitAll) — and
     exits non-zero if the box has fewer than N devices.  It never falls back to fewer GPUs than asked for.
 
 What the JSON line carries besides the contract's fields:
-  roofline               the dominant kernel of the timed region (k_path<false>: 98 % of the GPU time): bound "hbm" as the metric's name
-                         asks — achieved = fabric-side bytes the counters saw per ray (committed rocprofv3 --pmc passes of this very
-                         command, hash-checked against the device sources) x this run's rays/s of the kernel (HIP events); the
-                         algorithmic-bytes figure of SURVEY.md 8(d) beside it (it exceeds the peak on this cache-resident scene), and
-                         what really binds the kernel: vector-ALU issue (`valu_issue` sub-block).
-  roofline_hbm_resident  the same kernel on the ~10 M-triangle stand-in of BASELINE config 4 (BVH 0.6 GB > 256 MB Infinity Cache).
+  roofline               the dominant kernel of the timed region (k_path<false>: 98 % of the GPU time): `bound` names what binds it ("valu_issue" on this
+                         scene); achieved / frac / traffic are what the metric's name asks for and `frac_of` says so: fabric-side bytes the counters saw
+                         per ray (committed rocprofv3 --pmc passes of this very command, hash-checked against the device sources) x this run's rays/s of
+                         the kernel (HIP events) / 8 TB/s; the algorithmic-bytes figure of SURVEY.md 8(d) beside it (it exceeds the peak on this
+                         cache-resident scene); sub-block `valu_issue`: issue cycles of the kernel's EXECUTED instruction mix against 1024 SIMDs x the clock
+                         sampled inside the launches, as a range over the two rate tables.
+  roofline_hbm_resident  the same kernel on the ~10 M-triangle stand-in of BASELINE config 4 (BVH 0.6 GB > 256 MB Infinity Cache), priced against the
+                         measured roof of its access pattern (gather_roof_GBs: random dependent 80-byte gathers, tools/microbench/gather_roof.hip).
   primary_only           BASELINE config 2: primary rays only (adypt_trace_primary), >= 100 calls.
   tmp_lifetime_1         the K steps with every frame tracing its primary rays (report tmpLifetime 16 and 1).
-  single_frame           one adypt_trace_spp(ctx, 1) per call (what Instance::Update does), with the library's look-ahead.
+  single_frame           one adypt_trace_spp(ctx, 1) per call (what Instance::Update does), with the library's look-ahead; one_frame_per_pass: single frames
+                         in a row (frames_in_flight 1) in one call, in synchronous calls, and in calls with one frame started ahead.
   cpu_baseline           oracle/liboracle.so on the host cores, bounded sample.
 
 Scene: the real sponza.obj is not available anywhere (no network); a deterministic procedural stand-in of the same triangle count is
