@@ -115,6 +115,9 @@ public:
 	// frame traces a whole wavefront pass of N frames and the following N - 1 calls only apply their running-mean step — 1.4x the
 	// rays per second (DESIGN.md §4 "one frame per call"), but bursty: one call in N takes N frames' time, and the queues grow to
 	// N frames in flight (8 x 16 B x N x pixels per device).  Images are bit-identical either way.
+	// 1 (a good default for a window): still one frame per wavefront pass and the smallest queues, but the frame after the one asked for is STARTED on a
+	// second HIP stream before the call returns (under the end of the current frame's launch: +15 % at 1080p, even pacing); it is dropped when the camera
+	// moves, a viewer frame is traced or the sample counter is reset.
 	bool Initialize(const InstanceConfig::PT *config, const Scene &scene, const WideBVH &bvh, int width, int height,
 	                const std::vector<int> &devices = std::vector<int>(1, 0), int lookahead_frames = 0)
 	{
