@@ -20,7 +20,7 @@
 
 int main(int argc, char **argv)
 {
-	if(argc < 4) { fprintf(stderr, "usage: %s scene.config out.exr SPP [fp16]\n", argv[0]); return 2; }
+	if(argc < 4) { fprintf(stderr, "usage: %s scene.config out.exr SPP [fp16 [lookahead_frames]]\n", argv[0]); return 2; }
 	InstanceConfig config;
 	if(!config.LoadFromFile(argv[1])) { fprintf(stderr, "invalid config %s\n", argv[1]); return 1; }
 	Scene scene;
@@ -33,8 +33,10 @@ int main(int argc, char **argv)
 		WideBVHBuilder{config.m_bvh_cfg, &wbvh, sbvh}.Run();
 	}
 	HipPathTracer tracer;
-	// headless: look-ahead on (a pass of up to 32 frames per traced call), as a render-to-EXR loop would use it
-	if(!tracer.Initialize(&config.m_pt_cfg, scene, wbvh, config.m_width, config.m_height, std::vector<int>(1, 0), 32)) return 1;
+	// headless: look-ahead on (a pass of up to 32 frames per traced call), as a render-to-EXR loop would use it; 1 = what a window would use (one frame
+	// per pass, the next one started ahead on a second stream); 0 = strictly one frame per call
+	const int lookahead_frames = argc > 5 ? atoi(argv[5]) : 32;
+	if(!tracer.Initialize(&config.m_pt_cfg, scene, wbvh, config.m_width, config.m_height, std::vector<int>(1, 0), lookahead_frames)) return 1;
 	// Camera::GetView / GetProjection (src/Tracer/Camera.cpp:13-23; Camera.cpp itself needs GLFW and ImGui for Control())
 	const InstanceConfig::Cam &cam = config.m_cam_cfg;
 	glm::mat4 view = glm::rotate(glm::identity<glm::mat4>(), glm::radians(-cam.m_pitch), glm::vec3(1.0f, 0.0f, 0.0f));

@@ -37,13 +37,14 @@ def _require_ref_binaries():
                 "them from (they are built in the build container by __graft_entry__.build() and shipped with the gpurun snapshot)")
 
 
-@pytest.mark.parametrize("name,w,h,spp", [("tiny0", 96, 64, 5), ("sibenik", 160, 90, 3)])
-def test_reference_cpu_half_plus_this_library_equals_the_product_pipeline(name, w, h, spp, tmp_path):
+@pytest.mark.parametrize("name,w,h,spp,lookahead", [("tiny0", 96, 64, 5, 32), ("sibenik", 160, 90, 3, 32), ("tiny0", 96, 64, 7, 1), ("tiny0", 96, 64, 4, 0)])
+def test_reference_cpu_half_plus_this_library_equals_the_product_pipeline(name, w, h, spp, lookahead, tmp_path):
     _require_ref_binaries()
     from adypt_amd import scenes
     spec = scenes.make_scene(name, str(tmp_path), width=w, height=h, pt={"maxBounce": 5, "stackSize": 24, "tmpLifetime": 2})
     ref_exr, our_exr = str(tmp_path / "dropin.exr"), str(tmp_path / "ours.exr")
-    r = subprocess.run([DROPIN, spec.config_path, ref_exr, str(spp)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    # (lookahead 32: whole passes traced ahead; 1: one frame per pass, the next one started ahead on a second stream; 0: strictly one frame per call)
+    r = subprocess.run([DROPIN, spec.config_path, ref_exr, str(spp), "0", str(lookahead)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0 and ("[DROPIN]spp %d" % spp).encode() in r.stdout, (r.stdout + r.stderr).decode()[-2000:]
     r = subprocess.run([CLI, spec.config_path, "--spp", str(spp), "--out", our_exr, "--seed", "12345"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr).decode()[-2000:]
