@@ -220,10 +220,11 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		od_x = v2(ox, dir.x); od_y = v2(oy, dir.y); od_z = v2(oz, dir.z);
 	};
 
-	// the two base pointers of the trip's loads, held in SGPRs for the whole loop (as plain kernel arguments the compiler re-loads them from the
-	// kernarg segment inside the trip: a scalar load and its wait in front of every node / triangle fetch)
-	const float4 *trip_woop = a.woop;
-	const uint4 *trip_nodes = a.nodes;
+	// the two base pointers of the trip's loads, pinned for the whole loop (as plain kernel arguments the compiler re-loads them from the kernarg
+	// segment inside the trip: a scalar load and its wait in front of every node / triangle fetch) — as GLOBAL pointers: laundered as generic ones the
+	// eight loads of a trip became flat_load, which also passes through the LDS queue (-0.6 %, profiles/r5_ablations.txt 6)
+	GlobalF4 trip_woop = (GlobalF4)a.woop;
+	GlobalU4 trip_nodes = (GlobalU4)a.nodes;
 	asm volatile("" : "+s"(trip_woop), "+s"(trip_nodes));
 
 	// Shape of the loop: NO `continue`.  Every iteration runs top to bottom — start rays, exchange, trip — and a wave-uniform flag skips the

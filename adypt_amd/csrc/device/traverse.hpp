@@ -24,6 +24,17 @@
 
 namespace adypt {
 
+// 16-byte records of the trip's two tables through a pointer that KEEPS the global address space (k_path launders its base pointers through an empty
+// asm to pin them; as generic pointers the loads would become flat_load, which also occupies the LDS queue) or through a plain one (k_trace)
+typedef float NativeF4 __attribute__((ext_vector_type(4)));
+typedef uint32_t NativeU4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) NativeF4 *GlobalF4;
+typedef const __attribute__((address_space(1))) NativeU4 *GlobalU4;
+__device__ __forceinline__ float4 trip_ld(GlobalF4 p) { const NativeF4 v = *p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 trip_ld(GlobalU4 p) { const NativeU4 v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 trip_ld(const float4 *p) { return *p; }
+__device__ __forceinline__ uint4 trip_ld(const uint4 *p) { return *p; }
+
 constexpr int kRefillMin = 16; // default: refill when at least this many lanes of the wave are idle (or all are)
 constexpr int kChunk = 128;    // default: rays a workgroup reserves per queue atomic
 constexpr int kBite = 32;      // default: rays a wave takes from its workgroup's reservation at a time (end of a launch)
