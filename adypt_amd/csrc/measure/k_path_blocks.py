@@ -59,10 +59,10 @@ TRIP_EDITS = [
     ("			if(push_ok)\n			{\n				if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);\n				else my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y);\n				++sp;",
      "			if(push_ok)\n			{\n				" + enter("A_push") + "\n				if(sp < a.lds_depth) my_stack[sp * 64] = make_uint2(ng_x, ng_y);\n				else { " + enter("A_push_spill") + " my_spill[(size_t)(sp - a.lds_depth) * total_lanes] = make_uint2(ng_x, ng_y); " + leave("A_push_spill") + " }\n				++sp;"),
     ("				if(STATS) depth_after_push = (uint32_t)sp;\n			}", "				if(STATS) depth_after_push = (uint32_t)sp;\n				" + leave("A_push") + "\n			}"),
-    ("			if(do_test)\n			{\n				const float4 *w0 = trip_woop", "			if(do_test)\n			{\n				" + enter("B_tri_load") + "\n				const float4 *w0 = trip_woop"),
-    ("				wp0 = w0[0]; wp1 = w0[1]; wp2 = w0[2];\n			}", "				wp0 = w0[0]; wp1 = w0[1]; wp2 = w0[2];\n				" + leave("B_tri_load") + "\n			}"),
-    ("			if(pending && tg_y == 0)\n			{\n				const uint4 *np = trip_nodes", "			if(pending && tg_y == 0)\n			{\n				" + enter("B_node_load") + "\n				const uint4 *np = trip_nodes"),
-    ("				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];\n			}", "				n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];\n				" + leave("B_node_load") + "\n			}"),
+    ("			if(do_test)\n			{\n				const auto w0 = trip_woop", "			if(do_test)\n			{\n				" + enter("B_tri_load") + "\n				const auto w0 = trip_woop"),
+    ("				wp0 = trip_ld(w0); wp1 = trip_ld(w0 + 1); wp2 = trip_ld(w0 + 2);\n			}", "				wp0 = trip_ld(w0); wp1 = trip_ld(w0 + 1); wp2 = trip_ld(w0 + 2);\n				" + leave("B_tri_load") + "\n			}"),
+    ("			if(pending && tg_y == 0)\n			{\n				const auto np = trip_nodes", "			if(pending && tg_y == 0)\n			{\n				" + enter("B_node_load") + "\n				const auto np = trip_nodes"),
+    ("				n0 = trip_ld(np); n1 = trip_ld(np + 1); n2 = trip_ld(np + 2); n3 = trip_ld(np + 3); n4 = trip_ld(np + 4);\n			}", "				n0 = trip_ld(np); n1 = trip_ld(np + 1); n2 = trip_ld(np + 2); n3 = trip_ld(np + 3); n4 = trip_ld(np + 4);\n				" + leave("B_node_load") + "\n			}"),
     ("			if(do_test)\n			{\n				if(STATS) wave_event(2);", "			if(do_test)\n			{\n				" + enter("C_woop") + "\n				if(STATS) wave_event(2);"),
     ("				geom_ok = tt > t_tmin && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f;\n			}", "				geom_ok = tt > t_tmin && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f;\n				" + leave("C_woop") + "\n			}"),
     ("				pending = false;\n				if(ANY) overflow |= push_overflow;", "				" + enter("D_slab") + "\n				pending = false;\n				if(ANY) overflow |= push_overflow;"),
