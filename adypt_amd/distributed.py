@@ -20,7 +20,22 @@ from . import _native as N
 BLOCK = 32
 BLOCK_PIXELS = BLOCK * BLOCK
 import time as _time
-_PROCESS_START = _time.time()  # (import time of this module: bench.py imports it before the scene is built)
+
+
+def _launcher_start_time() -> float:
+    """Wall-clock time at which this process's PARENT started (the launcher all ranks of a torch.distributed.run job share), 0.0 when /proc does not say.
+    An id file older than that cannot belong to this job — whereas a rank's own start time would not do: the ranks of one job reach this point seconds apart
+    (a fresh box pages the libraries in for the first rank), and a slow rank must not take rank 0's fresh file for a stale one."""
+    import os
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            fields = f.read().rsplit(")", 1)[1].split()
+        ticks = int(fields[19])  # starttime: field 22 of /proc/pid/stat, in clock ticks since boot
+        with open("/proc/uptime") as f:
+            uptime = float(f.read().split()[0])
+        return _time.time() - uptime + ticks / float(os.sysconf("SC_CLK_TCK"))
+    except (OSError, ValueError, IndexError):
+        return 0.0
 
 
 def block_count(width: int, height: int, rank: int, world: int) -> int:
@@ -183,8 +198,8 @@ def exchange_unique_id(rank: int, world: int, path: Optional[str] = None, make_i
                     raise RuntimeError("rendezvous file %s belongs to another user" % path)
                 uid = f.read()
             # an id left behind by an EARLIER job that died before rank 0 could remove it (same launcher port, back-to-back runs) must not be taken
-            # for this job's: only a file written after this process started counts (rank 0 writes its id seconds after the ranks start)
-            if st.st_mtime < _PROCESS_START - 5.0:
+            # for this job's: only a file written after this job's LAUNCHER started counts
+            if st.st_mtime < _launcher_start_time() - 2.0:
                 uid = b""
             if len(uid) == 128:
                 return uid

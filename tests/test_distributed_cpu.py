@@ -165,7 +165,7 @@ def test_a_stale_id_of_an_earlier_job_is_not_taken_for_this_jobs(tmp_path):
     path = str(tmp_path / "id")
     with open(path, "wb") as f:
         f.write(b"\xee" * 128)
-    old = time.time() - 3600
+    old = time.time() - 30 * 86400  # (older than this test's parent process, the launcher stand-in)
     os.utime(path, (old, old))
     with pytest.raises(TimeoutError):
         D.exchange_unique_id(1, 2, path=path, timeout_s=0.5)         # the stale id is not returned
