@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -158,14 +159,18 @@ public:
 	GatherWatchdog(double timeout_s, std::function<std::string()> state) : stage_("start")
 	{
 		if(!(timeout_s > 0.0)) return;
-		thread_ = std::thread([this, timeout_s, state] {
-			std::unique_lock<std::mutex> lock(m_);
-			if(cv_.wait_for(lock, std::chrono::duration<double>(timeout_s), [this] { return done_; })) return;
-			fprintf(stderr, "[adypt] gather watchdog: the radiance gather has not finished after %.1f s (stage: %s)\n%s[adypt] exiting the process with code 86 (a collective cannot be cancelled)\n",
-					timeout_s, stage_.load(), state().c_str());
-			fflush(stderr);
-			_exit(86);
-		});
+		try
+		{
+			thread_ = std::thread([this, timeout_s, state] {
+				std::unique_lock<std::mutex> lock(m_);
+				if(cv_.wait_for(lock, std::chrono::duration<double>(timeout_s), [this] { return done_; })) return;
+				fprintf(stderr, "[adypt] gather watchdog: the radiance gather has not finished after %.1f s (stage: %s)\n%s[adypt] exiting the process with code 86 (a collective cannot be cancelled)\n",
+						timeout_s, stage_.load(), state().c_str());
+				fflush(stderr);
+				_exit(86);
+			});
+		}
+		catch(const std::exception &) {} // (no thread to be had: the gather runs unwatched — no exception crosses the C boundary)
 	}
 	~GatherWatchdog()
 	{
@@ -337,7 +342,13 @@ int adypt_create_multi(adypt_multi **out, const adypt_scene_desc *desc, const in
 	else
 	{
 		std::vector<std::thread> workers;
-		for(int i = 0; i < n_dev; ++i) workers.emplace_back(create_one, i);
+		std::vector<char> started((size_t)n_dev, 0);
+		for(int i = 0; i < n_dev; ++i)
+		{
+			try { workers.emplace_back(create_one, i); started[(size_t)i] = 1; }
+			catch(const std::exception &) {} // (no thread to be had: that device's context is created on this thread below)
+		}
+		for(int i = 0; i < n_dev; ++i) if(!started[(size_t)i]) create_one(i);
 		for(std::thread &t : workers) t.join();
 	}
 	for(int i = 0; i < n_dev; ++i)

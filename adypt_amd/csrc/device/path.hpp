@@ -114,6 +114,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	// persistent loop they would push the loop's own scalars into spills.
 	const PathArgs &a = K.a;
 	constexpr bool ANY = false;
+	constexpr bool kOverflowPerRay = false;
 	constexpr bool kUniformTmin = true; // every ray of the pass has the pass's tmin
 	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64] | path table [kTabFields][kPathSlots] | parking [kParkDwords][64] | to-shade, to-trace rings | PathCtl
 	const int lane = threadIdx.x & 63;

@@ -204,6 +204,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 		if(lane == (int)__builtin_ctzll(m)) { wp[slot] += 1; wp[slot + 1] += (unsigned long long)__popcll(m); }
 	};
 
+	constexpr bool kOverflowPerRay = true;
 	const float4 *const trip_woop = a.woop; // (the trip's two base pointers: traverse_trip.inc)
 	const uint4 *const trip_nodes = a.nodes;
 	for(;;)
