@@ -21,6 +21,10 @@
 //     of the records, made once at upload), so the uTriIndices remap (traversal.glsl:253-254) — a dependent load in front of every deposit —
 //     disappears from this kernel; the triangle id itself is never an output of these bounces.  A context without that copy (too large, or
 //     the allocation failed) passes uTriIndices as PathArgs::tri_remap and the shading round applies it;
+//   * a shading round runs every branch of Render()'s illum switch some lane needs, and the glossy lobe (two fp64 pow series and a sincos) or the
+//     dielectric branch are needed by a few lanes of almost every round: a round that finds such hits among the 64 it took DEFERS them to a second
+//     small ring (the class is a flag in the triangle record, known when the record arrives) and shades the others without those branches; when the
+//     ring holds rare_min of them a round takes them together.  A grouping of the work only: every path is shaded by the same arithmetic;
 //   * no inter-workgroup communication of any kind, so none of the cross-XCD visibility questions of a streaming queue.
 // The kernel ends when the global queue is dry and every workgroup has finished the paths it holds.
 #pragma once
@@ -34,6 +38,7 @@ namespace adypt {
 constexpr int kPathSlots = ADYPT_PATH_SLOTS;     // paths a workgroup holds: its 256 lanes' + those ready or waiting to be shaded (tuning: tools/build_variant.sh)
 static_assert(kPathSlots >= kTraceThreads && kPathSlots <= 2 * kTraceThreads && kPathSlots % 32 == 0, "k_path: 256 <= slots <= 512");
 constexpr int kTabFields = 10;                   // path word | direction | throughput | origin (to-trace) or hit (to-shade)
+constexpr int kRareCap = 96;                     // entries of the ring of deferred hits (glossy lobe / dielectric): what does not fit is shaded at once
 constexpr int kParkDwords = 10;                  // per-lane ray state a shading wave parks in LDS for the round (hit, groups, node, slot | stack pointer)
 constexpr uint32_t kPwBounceShift = 26;          // path word in the table: bits 25..0 path id, 30..26 bounce index, 31 radiance parked
 constexpr uint32_t kPwIdMask = (1u << kPwBounceShift) - 1u;
@@ -41,9 +46,9 @@ constexpr int64_t kPathMaxPaths = (int64_t)1 << kPwBounceShift; // batches with 
 enum { T_PW = 0, T_DX, T_DY, T_DZ, T_CX, T_CY, T_CZ, T_OX, T_OY, T_OZ };
 
 struct PathCtl {                                 // workgroup control block in LDS (zeroed at start)
-	uint32_t n_shade, n_trace, live, busy;         // deposited hits, ready rays, paths alive in this workgroup, a wave is shading   <- one 16-byte peek
+	uint32_t n_shade, n_trace, live, busy;         // deposited hits, ready rays, paths alive in this workgroup, (bit 0: a wave is shading | deferred hits << 16)   <- one 16-byte peek
 	uint32_t h_shade, h_trace, rays, shaded;       // heads of the two rings (FIFO: no path waits behind younger ones)
-	uint32_t lock, init_have, pad[6];
+	uint32_t lock, init_have, h_rare, pad[5];      // head of the ring of deferred hits (its count lives in `busy`)
 };
 
 struct PathArgs {
@@ -59,6 +64,7 @@ struct PathArgs {
 	uint32_t seg_cap;
 	int32_t stack_size, lds_depth;
 	uint32_t refill_min, shade_min;
+	uint32_t rare_min;             // deferred hits (glossy lobe / dielectric) a shading round waits for; 0 = no round defers anything
 	int32_t b0;                    // bounce index of the queue's rays (1: k_shade_first did bounce 0)
 	float tmin;
 };
@@ -66,7 +72,7 @@ struct PathArgs {
 inline size_t path_lds_bytes(int lds_depth)
 {
 	return (size_t)(kTraceThreads / 64) * (size_t)lds_depth * 64 * sizeof(uint2) + (size_t)kTabFields * kPathSlots * 4 + (size_t)kParkDwords * 64 * 4 + 2 * (size_t)kPathSlots * 2 +
-	       sizeof(PathCtl);
+	       (size_t)kRareCap * 2 + sizeof(PathCtl);
 }
 
 __device__ __forceinline__ void wg_lock(PathCtl *ctl, int lane)
@@ -116,14 +122,15 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	constexpr bool ANY = false;
 	constexpr bool kOverflowPerRay = false;
 	constexpr bool kUniformTmin = true; // every ray of the pass has the pass's tmin
-	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64] | path table [kTabFields][kPathSlots] | parking [kParkDwords][64] | to-shade, to-trace rings | PathCtl
+	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64] | path table [kTabFields][kPathSlots] | parking [kParkDwords][64] | to-shade, to-trace, deferred rings | PathCtl
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
 	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
 	uint32_t *tab = (uint32_t *)(lds_stack + (size_t)(kTraceThreads / 64) * a.lds_depth * 64);
 	uint32_t *park = tab + kTabFields * kPathSlots;
 	uint16_t *to_shade = (uint16_t *)(park + kParkDwords * 64), *to_trace = to_shade + kPathSlots;
-	PathCtl *ctl = (PathCtl *)(to_trace + kPathSlots);
+	uint16_t *to_rare = to_trace + kPathSlots;
+	PathCtl *ctl = (PathCtl *)(to_rare + kRareCap);
 	const uint32_t total_lanes = gridDim.x * (uint32_t)kTraceThreads;
 	const SpillColumn<true> my_spill(a.spill); // (addressed where it is used: traverse.hpp)
 	const int home = blockIdx.x & (kNumSegments - 1);
@@ -267,9 +274,11 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 			// a look at the lists without the lock (a hint: everything is decided again under it)
 			asm volatile("" ::: "memory"); // (read the control block afresh)
 			const uint4 pk = *(const uint4 *)&ctl->n_shade;
-			const uint32_t pk_shade = uni(pk.x), pk_trace = uni(pk.y), pk_live = uni(pk.z), pk_busy = uni(pk.w);
+			const uint32_t pk_shade = uni(pk.x), pk_trace = uni(pk.y), pk_live = uni(pk.z), pk_busy = uni(pk.w) & 1u, pk_rare = uni(pk.w) >> 16;
 			const uint32_t pk_thr = min(a.shade_min, max(1u, pk_live >> 2));
-			if(n_flush != 0u || pk_trace != 0u || (pk_shade + n_flush >= pk_thr && !pk_busy))
+			const bool pk_full = pk_thr == a.shade_min && pk_live >= a.shade_min + a.rare_min; // (the rule under the lock, below)
+			const bool pk_ready = pk_full ? (pk_shade + n_flush >= pk_thr || (pk_rare != 0u && pk_rare >= a.rare_min)) : pk_shade + pk_rare + n_flush >= pk_thr;
+			if(n_flush != 0u || pk_trace != 0u || (pk_ready && !pk_busy))
 			{
 				// Everything in this block runs at raised issue priority: while a wave is in here its rays do not advance, and at the fair share
 				// of a SIMD's issue slots (1 / 6) the block's few hundred instructions would keep it away from them several times longer
@@ -286,14 +295,34 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				n_s += n_flush;
 				flush = false;
 				const uint32_t thr = min(a.shade_min, max(1u, lv >> 2)); // fewer than 4 batches of paths left: smaller batches, down to single paths
-				const bool do_shade = n_s >= thr && n_s != 0u && uni(ctl->busy) == 0u; // one shading wave per workgroup at a time: one parking area
-				uint32_t take = 0, sslot = 0;
+				// Which hits the round takes.  While the workgroup holds 4 full batches or more (thr == shade_min): the deferred ones once rare_min of
+				// them wait, else the oldest 64 of the to-shade ring.  Below that (the launch is ending): whatever waits in either ring, deferred first.
+				// (live >= shade_min + rare_min: with every path of the workgroup waiting in the two rings, one of them has reached its threshold)
+				const uint32_t bw = uni(ctl->busy);
+				uint32_t n_r = bw >> 16, h_r = uni(ctl->h_rare);
+				auto ring_r = [](uint32_t i) { return i >= (uint32_t)kRareCap ? i - (uint32_t)kRareCap : i; };
+				const bool full_thr = thr == a.shade_min && lv >= a.shade_min + a.rare_min;
+				uint32_t take_r = 0, take_s = 0;
+				if((bw & 1u) == 0u) // one shading wave per workgroup at a time: one parking area
+				{
+					if(full_thr)
+					{
+						if(n_r != 0u && n_r >= a.rare_min) take_r = min(64u, n_r);
+						else if(n_s >= thr) take_s = min(64u, n_s);
+					}
+					else if(n_s + n_r >= thr && n_s + n_r != 0u) { take_r = min(64u, n_r); take_s = min(64u - take_r, n_s); }
+				}
+				const uint32_t take = take_r + take_s;
+				const bool do_shade = take != 0u;
+				const bool may_defer = full_thr && take_r == 0u && a.rare_min != 0u; // (wave-uniform) a round of the to-shade ring's hits, not at the launch's end
+				uint32_t sslot = 0;
 				if(do_shade)
 				{
-					take = min(64u, n_s);
-					if((uint32_t)lane < take) sslot = to_shade[ring(h_s + (uint32_t)lane)];
-					h_s = ring(h_s + take); n_s -= take;
-					if(lane == 0) { ctl->h_shade = h_s; ctl->busy = 1u; }
+					if((uint32_t)lane < take_r) sslot = to_rare[ring_r(h_r + (uint32_t)lane)];
+					else if((uint32_t)lane < take) sslot = to_shade[ring(h_s + (uint32_t)lane - take_r)];
+					h_s = ring(h_s + take_s); n_s -= take_s;
+					h_r = ring_r(h_r + take_r); n_r -= take_r;
+					if(lane == 0) { ctl->h_shade = h_s; ctl->h_rare = h_r; ctl->busy = 1u | (n_r << 16); }
 				}
 				else
 				{
@@ -321,7 +350,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					*(uint4 *)(pk_lane + 1 * 256) = make_uint4(ng_x, ng_y, tg_x, tg_y);
 					*(uint2 *)(park + 2 * 256 + lane_here * 2) = make_uint2(node, ray | ((uint32_t)sp << 16));
 					asm volatile("" ::: "memory");
-					const bool have = (uint32_t)lane < take;
+					bool have = (uint32_t)lane < take;
 					uint32_t pw = 0;
 					F3 dir = f3(0, 0, 1), color = f3(0, 0, 0), origin = f3(0, 0, 0), ret = f3(0, 0, 0), ret_in = f3(0, 0, 0);
 					int32_t tri_idx = -1;
@@ -332,6 +361,28 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 						dir = f3(__uint_as_float(tab[T_DX * kPathSlots + sslot]), __uint_as_float(tab[T_DY * kPathSlots + sslot]), __uint_as_float(tab[T_DZ * kPathSlots + sslot]));
 						color = f3(__uint_as_float(tab[T_CX * kPathSlots + sslot]), __uint_as_float(tab[T_CY * kPathSlots + sslot]), __uint_as_float(tab[T_CZ * kPathSlots + sslot]));
 						tri_idx = (int32_t)tab[T_OX * kPathSlots + sslot]; tu = __uint_as_float(tab[T_OY * kPathSlots + sslot]); tv = __uint_as_float(tab[T_OZ * kPathSlots + sslot]);
+					}
+					// the hit's triangle record: issued now, and — in a round that may defer — looked at before anything else is decided
+					TriCore tc;
+#pragma unroll
+					for(int i = 0; i < 20; ++i) tc.v[i] = 0.0f;
+					if(have && tri_idx != -1)
+					{
+						if(a.tri_remap) tri_idx = a.tri_remap[tri_idx]; // (contexts without the per-reference copy of the triangle records)
+						tc = load_tri_core(sc, tri_idx);
+					}
+					if(may_defer)
+					{
+						const bool rare = have && tri_idx != -1 && __float_as_uint(tc.v[19]) != 0u; // glossy lobe or dielectric (tracer.hip: the record's class word)
+						const unsigned long long rm = __ballot(rare);
+						if(rm != 0ull)
+						{
+							const uint32_t room = (uint32_t)kRareCap - n_r, rr = lane_rank(rm);
+							const bool defer = rare && rr < room;
+							if(defer) to_rare[ring_r(h_r + n_r + rr)] = (uint16_t)sslot; // (this wave owns the ring while it is the shading wave; the count is published under the lock below)
+							n_r += min((uint32_t)__popcll(rm), room);
+							have = have && !defer;
+						}
 					}
 					const int b = (int)((pw >> kPwBounceShift) & 31u);
 					const int pi = (int)(pw & kPwIdMask);
@@ -359,8 +410,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 						}
 						else
 						{
-							if(a.tri_remap) tri_idx = a.tri_remap[tri_idx]; // (contexts without the per-reference copy of the triangle records)
-							const SurfaceInfo si = fetch_info(f, sc, tri_idx, tu, tv);
+							const SurfaceInfo si = fetch_info(f, sc, tc, tri_idx, tu, tv);
 							origin = si.origin;
 							if(si.bad_mat) { alive = false; bad_mat = true; }
 							else
@@ -440,7 +490,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					n_t += n_push;
 					const uint32_t got = min(n_idle, n_t); // and the wave's own idle lanes take the oldest ready rays
 					if(!active && idle_rank < got) { ray = to_trace[ring(h_t + idle_rank)]; setup = true; }
-					if(lane == 0) { ctl->n_trace = n_t - got; ctl->h_trace = ring(h_t + got); if(n_lost) ctl->live = ctl->live - n_lost; ctl->busy = 0u; }
+					if(lane == 0) { ctl->n_trace = n_t - got; ctl->h_trace = ring(h_t + got); if(n_lost) ctl->live = ctl->live - n_lost; ctl->busy = n_r << 16; }
 					wg_unlock(ctl, lane);
 					asm volatile("; ADYPT_MARK shade_end");
 				}

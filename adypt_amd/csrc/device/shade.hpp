@@ -23,7 +23,7 @@
 // Per-local-pixel buffers (block-major, 32x32 blocks of 16 8x8 wave tiles): accum (RGBA32F running mean),
 // cache (primary hit: bits(tri), u, v, -), shift (2 bytes).
 // Scene triangles are repacked at upload from the 100-byte Triangle (src/Util/Shape.hpp:70-74) to 128 bytes =
-// 8 x float4: [p0 p1 p2 n0 n1 n2 | matid | pad] (5 x 16 B, always read) + [tc0 tc1 tc2 | pad] (2 x 16 B, textured only) + 16 B pad:
+// 8 x float4: [p0 p1 p2 n0 n1 n2 | matid | class word] (5 x 16 B, always read; class word: 1 = glossy lobe or dielectric, what k_path's shading rounds defer) + [tc0 tc1 tc2 | pad] (2 x 16 B, textured only) + 16 B pad:
 // one 128-byte line per gather (at 112 bytes a record straddled two lines three times out of four).
 #pragma once
 #include "canon_math.hpp"
@@ -405,10 +405,9 @@ __device__ __forceinline__ void finish_path(const FrameArgs &f, const PixelArgs 
 // FetchInfo (pathtracer.glsl:73-100): what the surface at a hit is made of.  Depends on the hit alone (triangle, u, v) — not on the ray —
 // so the frames of one tmpLifetime group, which share their primary hit, share it too (k_shade_first).
 struct SurfaceInfo { F3 origin, normal, diffuse, specular, emission; int illum0; float shininess, ior; bool bad_mat; };
-__device__ __forceinline__ SurfaceInfo fetch_info(const FrameArgs &f, const SceneArgs &sc, int tri_idx, float tu, float tv)
+__device__ __forceinline__ SurfaceInfo fetch_info(const FrameArgs &f, const SceneArgs &sc, const TriCore &tc, int tri_idx, float tu, float tv)
 {
 	SurfaceInfo s;
-	const TriCore tc = load_tri_core(sc, tri_idx);
 	const float *tri = tc.v;
 	const int matid = __float_as_int(tri[18]);
 	// the hit's geometry before the material is looked at: all five loads of the record are then in flight together (with the
@@ -431,6 +430,11 @@ __device__ __forceinline__ SurfaceInfo fetch_info(const FrameArgs &f, const Scen
 		s.emission = f3(me.y, me.z, me.w);
 	}
 	return s;
+}
+
+__device__ __forceinline__ SurfaceInfo fetch_info(const FrameArgs &f, const SceneArgs &sc, int tri_idx, float tu, float tv)
+{
+	return fetch_info(f, sc, load_tri_core(sc, tri_idx), tri_idx, tu, tv);
 }
 
 // The rest of one iteration `b` of Render()'s loop (pathtracer.glsl:101-104, 144-201) at a surface with a valid material: emission picked

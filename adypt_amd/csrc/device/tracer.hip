@@ -182,6 +182,7 @@ struct adypt_ctx {
 	int path_blocks = 0, path_lds_depth = 0; // launch geometry of k_path
 	size_t path_lds = 0;
 	uint32_t shade_min = 64;       // deposited hits a wave of k_path waits for before it shades a batch
+	uint32_t rare_min = 48;        // deferred hits (glossy lobe / dielectric) a shading round of k_path waits for; 0 = nothing is deferred
 	int deal_chunks = 1;           // k_gen_primary deals 256-path chunks round-robin to the 8 queue segments (ADYPT_GEN_DEAL=0: one contiguous run each)
 
 	// state
@@ -406,7 +407,7 @@ int launch_path(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int pari
 	a.spill = pipe.spill; a.stats = c->d_stats;
 	a.seg_cap = win.seg_cap;
 	a.stack_size = c->params.stack_size; a.lds_depth = c->path_lds_depth;
-	a.refill_min = c->refill_min; a.shade_min = c->shade_min;
+	a.refill_min = c->refill_min; a.shade_min = c->shade_min; a.rare_min = c->rare_min;
 	a.b0 = b0; a.tmin = c->params.ray_tmin;
 	hipEvent_t *stop = begin_timing(c, 2, pipe.stream);
 	const PathKernArgs K{a, f, sc, px, stats ? 1 : 0};
@@ -888,6 +889,7 @@ Tunables read_tunables()
 	t.bite = (int)num("ADYPT_BITE", 1, 4096, 0); t.bite_primary = (int)num("ADYPT_BITE_PRIMARY", 1, 4096, 0);
 	t.chunk = (int)num("ADYPT_CHUNK", 16, 4096, 0); t.endgame = (int)num("ADYPT_ENDGAME", 0, 1024, -1);
 	t.shade_min = (int)num("ADYPT_SHADE_MIN", 1, 64, 0);
+	t.rare_min = (int)num("ADYPT_RARE_MIN", 0, 64, -1);
 	t.lds_stack_depth = (int)num("ADYPT_LDS_STACK_DEPTH", 1, kLdsStackMax, 0); t.trace_blocks_per_cu = (int)num("ADYPT_TRACE_BLOCKS_PER_CU", 1, 16, 0);
 	t.path_blocks_per_cu = (int)num("ADYPT_PATH_BLOCKS_PER_CU", 1, 8, 0); t.path_lds_depth = (int)num("ADYPT_PATH_LDS_DEPTH", 1, kLdsStackMax, 0);
 	t.path_verbose = flag("ADYPT_PATH_VERBOSE", 0);
@@ -998,6 +1000,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		c->deal_chunks = t.gen_deal; c->first_fused = t.first_fused; c->fused_bounces = t.fused_bounces; c->single_fused = t.single_fused;
 		c->audit_selftest = t.audit_selftest; c->single_overlap = t.single_overlap;
 		if(t.shade_min > 0) c->shade_min = (uint32_t)t.shade_min;
+		if(t.rare_min >= 0) c->rare_min = (uint32_t)t.rare_min;
 		if(t.chunk > 0) c->chunk = (uint32_t)t.chunk;
 		if(t.endgame >= 0) c->endgame = (uint32_t)t.endgame;
 		if(t.bite > 0) c->bite = c->bite_primary = (uint32_t)t.bite;
@@ -1034,6 +1037,17 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 			float *o = packed.data() + (size_t)i * kTriFloat4 * 4;
 			memcpy(o, src + i * 100, 72);            // positions + normals
 			memcpy(o + 18, src + i * 100 + 96, 4);   // material id
+			// class word (shade.hpp): 1 = a hit here runs the glossy lobe or the dielectric branch of Render() — what k_path's shading rounds defer to a
+			// round of their own (path.hpp).  A grouping hint only: never an input of the arithmetic.
+			int32_t matid; memcpy(&matid, src + i * 100 + 96, 4);
+			if(matid >= 0 && matid < d->n_mats)
+			{
+				const uint8_t *mat = (const uint8_t *)d->materials + (size_t)matid * 64;
+				int32_t dtex, illum; float shininess;
+				memcpy(&dtex, mat, 4); memcpy(&illum, mat + 48, 4); memcpy(&shininess, mat + 52, 4);
+				const uint32_t cls = material_class(illum, shininess, false), word = (cls == 3u || cls == 6u) ? 1u : 0u;
+				memcpy(o + 19, &word, 4);
+			}
 			memcpy(o + 20, src + i * 100 + 72, 24);  // texture coordinates
 		}
 		TRY_CREATE(upload(c, &c->d_triangles, packed.data(), packed.size()));

@@ -6,7 +6,7 @@ vector instructions per trip (profiles/r5_trip_budget.json, r5_k_path_block_coun
     tools/build_variant.sh blocks --transform adypt_amd/csrc/measure/k_path_blocks.py
 Three counting passes (twelve counters each: ADYPT_BLOCKS_SET = trip | shade | rare); every mark is inserted in every pass.  Blocks: setup | exchange | shade | trip;
 inside the trip A_pop (A_pop_spill) A_choose A_push (A_push_spill) B_tri_load B_node_load C_woop D_slab E_flush; inside a shading round S_parked S_miss S_surface
-(S_textured S_glossy S_diffuse S_mirror S_dielectric) S_dead S_alive S_replace S_early S_fetch_more; anywhere div_slow (the division sequence behind rcp_ieee's
+(S_textured S_glossy S_diffuse S_mirror S_dielectric) S_dead S_alive S_replace S_early S_fetch_more S_defer (a round moves glossy / dielectric hits to the deferred ring); inside the exchange X_pick | X_take (its two exclusive branches: a round follows, or rays are taken); anywhere div_slow (the division sequence behind rcp_ieee's
 range test), F_try (one try of fetch_rays at one queue segment) and X_lock_spin.  What lies inside a block but outside its sub-blocks runs whenever the block does."""
 import sys
 d = sys.argv[1]
@@ -17,8 +17,11 @@ SETS = {"trip": ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_p
         "shade": ["shade", "S_parked", "S_miss", "S_surface", "S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric", "S_dead", "S_alive", "S_replace"],
         # blocks expected to run (almost) never: stack entries beyond the LDS part, the division sequence behind rcp_ieee's range test (every site one
         # counter), the shading round's second and later reservations of replacement paths, its early reservation, the lock's spin
-        "rare": ["trip", "shade", "A_pop_spill", "A_push_spill", "div_slow", "S_fetch_more", "S_early", "X_lock_spin", "exchange", "setup", "F_try"]}
-NAMES = SETS[SET]
+        "rare": ["trip", "shade", "A_pop_spill", "A_push_spill", "div_slow", "S_fetch_more", "S_early", "X_lock_spin", "exchange", "setup", "F_try", "S_defer"]}
+LANES = os.environ.get("ADYPT_BLOCKS_LANES", "0") != "0"   # 1: the counters add up the ACTIVE LANES at each entry (s_bcnt1 of exec) instead of the entries: five 32-bit counters per pass
+SETS_LANES = {"trip": ["trip", "A_choose", "C_woop", "D_slab", "E_flush"], "shade": ["S_surface", "S_textured", "S_glossy", "S_diffuse", "S_dielectric"],
+              "rare": ["S_miss", "S_mirror", "S_dead", "S_alive", "S_replace"]}
+NAMES = SETS_LANES[SET] if LANES else SETS[SET]
 # Counters: a value that is modified inside a divergent block cannot live in an SGPR the compiler allocates (the merge after the block is per lane).
 # So k_path is held to 96 SGPRs (amdgpu_num_sgpr) and the counters live in s96 .. s101, touched only by inline assembly: two 16-bit counters per
 # register (a wave makes < 65536 trips per launch at the batch sizes measured).
@@ -38,6 +41,8 @@ def enter(n):  # the counter of block n goes up once per wave that enters the bl
     if n not in NAMES or not COUNT:
         return '__builtin_amdgcn_sched_barrier(0); asm volatile("; ADYPT_MARK %s_begin"); __builtin_amdgcn_sched_barrier(0);' % n
     i = NAMES.index(n)
+    if LANES:  # s96 .. s100 = lanes that entered block i, s101 = scratch
+        return '__builtin_amdgcn_sched_barrier(0); asm volatile("s_bcnt1_i32_b64 s101, exec\\n\\ts_add_u32 s%d, s%d, s101 ; ADYPT_MARK %s_begin" ::: "s%d", "s101", "scc"); __builtin_amdgcn_sched_barrier(0);' % (96 + i, 96 + i, n, 96 + i)
     return '__builtin_amdgcn_sched_barrier(0); asm volatile("s_add_u32 s%d, s%d, %s ; ADYPT_MARK %s_begin" ::: "s%d"); __builtin_amdgcn_sched_barrier(0);' % (96 + i // 2, 96 + i // 2, "0x10000" if i & 1 else "1", n, 96 + i // 2)
 
 
@@ -83,7 +88,9 @@ SHADE_PATH = [
     ("						if(parked) { const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); }", "						if(parked) { " + enter("S_parked") + " const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); " + leave("S_parked") + " }"),
     ("							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135\n							alive = false;",
      "							" + enter("S_miss") + "\n							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135\n							alive = false;\n							" + leave("S_miss")),
-    ("							if(a.tri_remap) tri_idx = a.tri_remap[tri_idx];", "							" + enter("S_surface") + "\n							if(a.tri_remap) tri_idx = a.tri_remap[tri_idx];"),
+    ("							const SurfaceInfo si = fetch_info(f, sc, tc, tri_idx, tu, tv);", "							" + enter("S_surface") + "\n							const SurfaceInfo si = fetch_info(f, sc, tc, tri_idx, tu, tv);"),
+    ("						if(rm != 0ull)\n						{", "						if(rm != 0ull)\n						{\n							" + enter("S_defer")),
+    ("							have = have && !defer;\n						}", "							have = have && !defer;\n							" + leave("S_defer") + "\n						}"),
     ("								alive = respond(f, si, rng, b, dir, color, ret);\n							}\n						}", "								alive = respond(f, si, rng, b, dir, color, ret);\n							}\n							" + leave("S_surface") + "\n						}"),
     ("						if(!alive) // main()'s clamp (pathtracer.glsl:224); the running mean is k_resolve's, in frame order (a k_path pass is always batched)\n							f.done[pi] = make_float4(gl_min(ret.x, f.clamp), gl_min(ret.y, f.clamp), gl_min(ret.z, f.clamp), 1.0f);",
      "						if(!alive) { " + enter("S_dead") + "\n							f.done[pi] = make_float4(gl_min(ret.x, f.clamp), gl_min(ret.y, f.clamp), gl_min(ret.z, f.clamp), 1.0f); " + leave("S_dead") + " }"),
@@ -111,6 +118,11 @@ pairs = SHADE_PATH + [
     ("							served += gn;\n						}", "							served += gn;\n							" + leave("S_fetch_more") + "\n						}"),
     ("			expect = 0u;\n			__builtin_amdgcn_s_sleep(1);", "			" + enter("X_lock_spin") + "\n			expect = 0u;\n			__builtin_amdgcn_s_sleep(1);\n			" + leave("X_lock_spin")),
     ('				asm volatile("; ADYPT_MARK exchange_begin");', "				" + enter("exchange")),
+    # the two exclusive branches under the lock (marks only: X_pick is entered exactly when a round follows = `shade`, X_take otherwise = `exchange` - `shade`)
+    ("				if(do_shade)\n				{\n					if((uint32_t)lane < take_r)", "				if(do_shade)\n				{\n					" + enter("X_pick") + "\n					if((uint32_t)lane < take_r)"),
+    ("					if(lane == 0) { ctl->h_shade = h_s; ctl->h_rare = h_r; ctl->busy = 1u | (n_r << 16); }\n				}\n				else\n				{",
+     "					if(lane == 0) { ctl->h_shade = h_s; ctl->h_rare = h_r; ctl->busy = 1u | (n_r << 16); }\n					" + leave("X_pick") + "\n				}\n				else\n				{\n					" + enter("X_take")),
+    ("					if(lane == 0 && got) { ctl->n_trace = n_t - got; ctl->h_trace = ring(h_t + got); }\n				}", "					if(lane == 0 && got) { ctl->n_trace = n_t - got; ctl->h_trace = ring(h_t + got); }\n					" + leave("X_take") + "\n				}"),
     ('					asm volatile("; ADYPT_MARK shade_begin");', "					" + enter("shade")),
     ('			asm volatile("; ADYPT_MARK setup_begin");', "			" + enter("setup")),
     ("		if(!skip_trip)\n#include \"traverse_trip.inc\"", "		if(!skip_trip)\n		{\n		" + enter("trip") + "\n#include \"traverse_trip.inc\"\n		" + leave("trip") + "\n		}"),
@@ -123,7 +135,7 @@ if COUNT:
         ("template <bool STATS>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathKernArgs K)\n{",
          "template <bool STATS>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) __attribute__((amdgpu_num_sgpr(96))) void k_path(PathKernArgs K)\n{\n	" + zero),
         ("	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------",
-         "	{ uint32_t bc[6]; " + read + "\n	if(lane == 0) for(int i = 0; i < 6; ++i) atomicAdd(&a.stats->wave_profile[i], (((unsigned long long)(bc[i] >> 16)) << 32) | (unsigned long long)(bc[i] & 0xffffu)); } // (k_path<false> leaves wave_profile alone)\n"
+         "	{ uint32_t bc[6]; " + read + "\n	if(lane == 0) for(int i = 0; i < 6; ++i) atomicAdd(&a.stats->wave_profile[i], " + ("(unsigned long long)bc[i]" if LANES else "(((unsigned long long)(bc[i] >> 16)) << 32) | (unsigned long long)(bc[i] & 0xffffu)") + "); } // (k_path<false> leaves wave_profile alone)\n"
          "	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------"),
     ]
 edit("path.hpp", pairs)

@@ -383,10 +383,18 @@ def write_zoo(tmp_path):
     return str(tmp_path / "zoo.obj"), mats
 
 
-def test_material_zoo_matches_oracle(tmp_path, sobol_matrices):
+@pytest.mark.parametrize("env", [
+    {},
+    {"ADYPT_RARE_MIN": "0"},                                                         # no shading round defers anything
+    {"ADYPT_PATH_BLOCKS_PER_CU": "1", "ADYPT_RARE_MIN": "64"},                       # long queues per workgroup: rounds defer, the deferred ring fills up and overflows
+    {"ADYPT_PATH_BLOCKS_PER_CU": "1", "ADYPT_RARE_MIN": "3", "ADYPT_SHADE_MIN": "9"},
+])
+def test_material_zoo_matches_oracle(env, tmp_path, sobol_matrices, monkeypatch):
     """Every branch of Render's illum switch (pathtracer.glsl:144-201) on the device: diffuse, glossy above and AT the e = Ns * 0.01 > 0.3
     threshold (falls through to diffuse), very sharp lobes, mirrors, dielectrics with Ni below / at / above 1, the values the switch does
     not name (0, 8, 9: the ray goes straight on), materials without illum (tinyobj default 0), emitters."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)   # (tunables are read at adypt_create)
     obj, mats = write_zoo(tmp_path)
     w, h = 96, 54
     sc, b, pt, p = _tracer(obj, w, h)

@@ -13,8 +13,11 @@ from adypt_amd import api, scenes, _native as N
 SET = os.environ.get("ADYPT_BLOCKS_SET", "trip")  # which counting variant ADYPT_LIB is: trip | shade | rare
 SETS = {"trip": ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_push", "B_tri_load", "B_node_load", "C_woop", "D_slab", "E_flush"],
         "shade": ["shade", "S_parked", "S_miss", "S_surface", "S_textured", "S_glossy", "S_diffuse", "S_mirror", "S_dielectric", "S_dead", "S_alive", "S_replace"],
-        "rare": ["trip", "shade", "A_pop_spill", "A_push_spill", "div_slow", "S_fetch_more", "S_early", "X_lock_spin", "exchange", "setup", "F_try"]}  # = adypt_amd/csrc/measure/k_path_blocks.py
-NAMES = SETS[SET]
+        "rare": ["trip", "shade", "A_pop_spill", "A_push_spill", "div_slow", "S_fetch_more", "S_early", "X_lock_spin", "exchange", "setup", "F_try", "S_defer"]}  # = adypt_amd/csrc/measure/k_path_blocks.py
+LANES = os.environ.get("ADYPT_BLOCKS_LANES", "0") != "0"  # the variant was built with ADYPT_BLOCKS_LANES=1: the counters hold active lanes, five per pass
+SETS_LANES = {"trip": ["trip", "A_choose", "C_woop", "D_slab", "E_flush"], "shade": ["S_surface", "S_textured", "S_glossy", "S_diffuse", "S_dielectric"],
+              "rare": ["S_miss", "S_mirror", "S_dead", "S_alive", "S_replace"]}
+NAMES = SETS_LANES[SET] if LANES else SETS[SET]
 scene = os.environ.get("SWEEP_SCENE", "sponza"); fr = int(os.environ.get("SWEEP_FRAMES", "20")); warm = int(os.environ.get("SWEEP_WARMUP", "5"))
 spec = scenes.make_scene(scene, os.environ.get("ADYPT_CACHE", "/tmp/adypt_cache"), width=1920, height=1080,
                          pt={"maxBounce": 8, "tmpLifetime": 16, "stackSize": 24, "subpixel": 8, "clamp": 4.0, "sun": [12.0, 11.0, 10.0]})
@@ -24,6 +27,12 @@ p.SetInstrumentation(timing=True)
 p.Trace(True, warm); p.DeviceSynchronize(); p.ResetStats()
 p.Trace(True, fr); p.DeviceSynchronize()
 s = p.GetStats(); w = list(p.GetWaveProfile().values())
+if LANES:
+    lanes = {n: int(w[i]) for i, n in enumerate(NAMES)}
+    print(json.dumps({"lib": os.path.basename(N.LIB_PATH), "set": SET, "scene": scene, "frames": fr, "warmup": warm, "k_path_rays": int(s["path_rays"]), "shaded": int(s.get("shaded", 0)),
+                      "lanes_entered": lanes, "lanes_per_ray": {n: round(c / max(1, s["path_rays"]), 5) for n, c in lanes.items()},
+                      "note": "lanes_entered[b] = active lanes (s_bcnt1 of exec) summed over every entry of a wave into block b"}))
+    sys.exit(0)
 counts = {}
 for i, n in enumerate(NAMES):
     v = w[i // 2]

@@ -40,6 +40,9 @@ for name in ("r5_k_path_shade_block_counts.json", "r5_k_path_rare_block_counts.j
     for k, v in e.items():
         w.setdefault(k, v * scale)
 
+# the two exclusive branches of the exchange carry marks but no counter: a round follows (= `shade`) or rays are taken (= `exchange` - `shade`)
+w.setdefault("X_pick", w["shade"]); w.setdefault("X_take", w["exchange"] - w["shade"])
+
 B = budget["blocks"]
 
 
