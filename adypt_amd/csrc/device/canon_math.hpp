@@ -12,6 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// a four-component register "defined" by an empty asm — no instruction — for values that are only read where a conditional load has written them
+#define ADYPT_DEF4(v) asm volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))
+
 namespace adypt {
 
 struct F3 { float x, y, z; };

@@ -362,18 +362,53 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 						color = f3(__uint_as_float(tab[T_CX * kPathSlots + sslot]), __uint_as_float(tab[T_CY * kPathSlots + sslot]), __uint_as_float(tab[T_CZ * kPathSlots + sslot]));
 						tri_idx = (int32_t)tab[T_OX * kPathSlots + sslot]; tu = __uint_as_float(tab[T_OY * kPathSlots + sslot]); tv = __uint_as_float(tab[T_OZ * kPathSlots + sslot]);
 					}
-					// the hit's triangle record: issued now, and — in a round that may defer — looked at before anything else is decided
+					const int b = (int)((pw >> kPwBounceShift) & 31u);
+					const int pi = (int)(pw & kPwIdMask);
+					bool parked = (pw & kPathParked) != 0u;
+					const bool last = b + 1 >= f.max_bounce; // the path ends with this iteration whatever it hits: respond() stops after the emission (the switch's outputs have no reader)
+					// Everything a round waits for that does not depend on another fetch is issued up front, back to back — the hit's triangle record, the
+					// reservation of the paths that replace those certain to end here (miss, or last bounce), the radiance parked so far, the pixel's shift
+					// bytes and the frame's Sobol point of this bounce — and lands behind ONE wait; the material and the texels follow (two more).  A shading
+					// wave is the one serial resource of its workgroup (64 paths every ~13 us at the bench rate): as the code stood, eight waits in a row.
+					// (the destinations are "defined" by an empty asm, not zero-filled: a zero fill is a copy after the conditional load, and the copy waits)
+					const int frame = (int)((uint32_t)pi / (uint32_t)f.n_local_px);
+					const int L = pi - frame * f.n_local_px;
 					TriCore tc;
 #pragma unroll
-					for(int i = 0; i < 20; ++i) tc.v[i] = 0.0f;
+					for(int i = 0; i < 20; ++i) asm volatile("" : "=v"(tc.v[i]));
 					if(have && tri_idx != -1)
 					{
 						if(a.tri_remap) tri_idx = a.tri_remap[tri_idx]; // (contexts without the per-reference copy of the triangle records)
 						tc = load_tri_core(sc, tri_idx);
 					}
+					// (a path certain to end is never deferred — on its last bounce it does not run the illum switch at all — so the count below holds after the deferral)
+					const bool sure = have && (tri_idx == -1 || last);
+					const uint32_t n_sure = (uint32_t)__popcll(__ballot(sure));
+					const bool early = n_sure != 0u && !((seg_done >> home) & 1u);
+					uint32_t rel;
+					asm volatile("" : "=v"(rel));
+					{
+						// (the index passes through a vector register the compiler cannot see through: for a uniform address its atomic optimizer wraps the
+						// one-lane atomic in a lane scan whose broadcast waits for the result on the spot — the latency this early issue is there to hide)
+						uint32_t cur = (uint32_t)home * (uint32_t)kCursorStride;
+						asm volatile("" : "+v"(cur));
+						if(early && lane == 0) rel = atomicAdd(&a.cursor[cur], n_sure);
+					}
+					float4 r4;
+					ADYPT_DEF4(r4);
+					uint32_t shift16;
+					float sob_x, sob_y;
+					asm volatile("" : "=v"(shift16), "=v"(sob_x), "=v"(sob_y));
+					if(have)
+					{
+						if(parked) r4 = f.done[pi];
+						shift16 = *(const uint16_t *)(px.shift + (size_t)L * 2);
+						const float2 sp2 = *(const float2 *)(f.sobol + frame * 64 + 2 * b);
+						sob_x = sp2.x; sob_y = sp2.y;
+					}
 					if(may_defer)
 					{
-						const bool rare = have && tri_idx != -1 && __float_as_uint(tc.v[19]) != 0u; // glossy lobe or dielectric (tracer.hip: the record's class word)
+						const bool rare = have && tri_idx != -1 && !last && __float_as_uint(tc.v[19]) != 0u; // glossy lobe or dielectric (tracer.hip: the record's class word)
 						const unsigned long long rm = __ballot(rare);
 						if(rm != 0ull)
 						{
@@ -384,24 +419,11 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 							have = have && !defer;
 						}
 					}
-					const int b = (int)((pw >> kPwBounceShift) & 31u);
-					const int pi = (int)(pw & kPwIdMask);
-					bool parked = (pw & kPathParked) != 0u;
-					// the paths that are certain to end here (miss, or this is the last bounce) are replaced from the global queue: their
-					// reservation is issued now and is back by the time the gathers below have returned
-					const bool sure = have && (tri_idx == -1 || b + 1 >= f.max_bounce);
-					const uint32_t n_sure = (uint32_t)__popcll(__ballot(sure));
-					const bool early = n_sure != 0u && !((seg_done >> home) & 1u);
-					uint32_t rel = 0;
-					if(early && lane == 0) rel = atomicAdd(&a.cursor[home * kCursorStride], n_sure);
 
 					bool alive = have, shaded = false, bad_mat = false;
-					int L = 0;
 					if(have)
 					{
-						const int frame = (int)((uint32_t)pi / (uint32_t)f.n_local_px);
-						L = pi - frame * f.n_local_px;
-						if(parked) { const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); }
+						if(parked) ret = f3(r4.x, r4.y, r4.z);
 						ret_in = ret;
 						if(tri_idx == -1)
 						{
@@ -416,8 +438,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 							else
 							{
 								shaded = true;
-								const uint8_t *shb = px.shift + (size_t)L * 2;
-								const Rng rng{unorm8_to_float(shb[0]), unorm8_to_float(shb[1]), f.sobol + frame * 64};
+								const RngPoint rng{unorm8_to_float(shift16 & 0xffu), unorm8_to_float(shift16 >> 8), sob_x, sob_y};
 								alive = respond(f, si, rng, b, dir, color, ret);
 							}
 						}

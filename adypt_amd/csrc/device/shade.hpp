@@ -371,7 +371,15 @@ __device__ __forceinline__ void sobol2(const Rng &r, int i, float *x, float *y)
 	const float a = r.sobol[2 * i] + r.sx, b = r.sobol[2 * i + 1] + r.sy;
 	*x = a - floorf(a); *y = b - floorf(b);
 }
-__device__ inline F3 sample_hemisphere(const Rng &rng, int b, float e)
+// the same with the frame's point of bounce `b` fetched by the caller (k_path issues that load with the round's other independent fetches)
+struct RngPoint { float sx, sy, qx, qy; };
+__device__ __forceinline__ void sobol2(const RngPoint &r, int, float *x, float *y)
+{
+	const float a = r.qx + r.sx, b = r.qy + r.sy;
+	*x = a - floorf(a); *y = b - floorf(b);
+}
+template <class RNG>
+__device__ inline F3 sample_hemisphere(const RNG &rng, int b, float e)
 {
 	float rx, ry; sobol2(rng, b, &rx, &ry);
 	rx *= 6.28318530718f;
@@ -439,7 +447,8 @@ __device__ __forceinline__ SurfaceInfo fetch_info(const FrameArgs &f, const Scen
 
 // The rest of one iteration `b` of Render()'s loop (pathtracer.glsl:101-104, 144-201) at a surface with a valid material: emission picked
 // up, the `illum` switch, the new direction and throughput.  Returns whether the path goes on.
-__device__ __forceinline__ bool respond(const FrameArgs &f, const SurfaceInfo &si, const Rng &rng, int b, F3 &dir, F3 &color, F3 &ret)
+template <class RNG>
+__device__ __forceinline__ bool respond(const FrameArgs &f, const SurfaceInfo &si, const RNG &rng, int b, F3 &dir, F3 &color, F3 &ret)
 {
 	bool alive = true;
 	F3 normal = si.normal;
@@ -447,6 +456,8 @@ __device__ __forceinline__ bool respond(const FrameArgs &f, const SurfaceInfo &s
 	const int illum0 = si.illum0;
 	const float shininess = si.shininess, ior = si.ior;
 	ret = fma3(color, si.emission, ret);
+	// last iteration of the loop (pathtracer.glsl:107): the switch below only produces the next direction and throughput, which nothing reads any more
+	if(b + 1 >= f.max_bounce) return false;
 	if(illum0 < 6 && dot3(dir, normal) > 0) normal = -normal;
 	int illum = illum0;
 	bool done = false;
@@ -507,7 +518,6 @@ __device__ __forceinline__ bool respond(const FrameArgs &f, const SurfaceInfo &s
 			else dir = reflect3(dir, normal);
 		}
 	}
-	if(b + 1 >= f.max_bounce) alive = false; // last loop iteration
 	return alive;
 }
 

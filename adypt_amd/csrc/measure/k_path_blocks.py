@@ -85,7 +85,7 @@ edit("canon_math.hpp", [("	return 1.0f / x;\n}", "	" + enter("div_slow") + "\n	c
 zero = " ".join('asm volatile("s_mov_b32 s%d, 0" ::: "s%d");' % (r, r) for r in range(96, 102))
 read = " ".join('asm volatile("s_mov_b32 %%0, s%d" : "=s"(bc[%d]));' % (96 + i, i) for i in range(6))
 SHADE_PATH = [
-    ("						if(parked) { const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); }", "						if(parked) { " + enter("S_parked") + " const float4 r4 = f.done[pi]; ret = f3(r4.x, r4.y, r4.z); " + leave("S_parked") + " }"),
+    ("						if(parked) r4 = f.done[pi];", "						if(parked) { " + enter("S_parked") + " r4 = f.done[pi]; " + leave("S_parked") + " }"),
     ("							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135\n							alive = false;",
      "							" + enter("S_miss") + "\n							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135\n							alive = false;\n							" + leave("S_miss")),
     ("							const SurfaceInfo si = fetch_info(f, sc, tc, tri_idx, tu, tv);", "							" + enter("S_surface") + "\n							const SurfaceInfo si = fetch_info(f, sc, tc, tri_idx, tu, tv);"),
@@ -109,11 +109,11 @@ SHADE_HPP = [
     ("		else if(illum >= 3 && illum <= 5)\n		{\n			color = color * specular;\n			dir = reflect3(dir, normal);\n		}",
      "		else if(illum >= 3 && illum <= 5)\n		{\n			" + enter("S_mirror") + "\n			color = color * specular;\n			dir = reflect3(dir, normal);\n			" + leave("S_mirror") + "\n		}"),
     ("		else if(illum == 6 || illum == 7)\n		{\n			float eta = ior;", "		else if(illum == 6 || illum == 7)\n		{\n			" + enter("S_dielectric") + "\n			float eta = ior;"),
-    ("			else dir = reflect3(dir, normal);\n		}\n	}\n	if(b + 1 >= f.max_bounce) alive = false; // last loop iteration", "			else dir = reflect3(dir, normal);\n			" + leave("S_dielectric") + "\n		}\n	}\n	if(b + 1 >= f.max_bounce) alive = false; // last loop iteration"),
+    ("			else dir = reflect3(dir, normal);\n		}\n	}\n	return alive;", "			else dir = reflect3(dir, normal);\n			" + leave("S_dielectric") + "\n		}\n	}\n	return alive;"),
 ]
 edit("shade.hpp", SHADE_HPP)
 pairs = SHADE_PATH + [
-    ("					if(early && lane == 0) rel = atomicAdd(&a.cursor[home * kCursorStride], n_sure);", "					if(early && lane == 0) { " + enter("S_early") + " rel = atomicAdd(&a.cursor[home * kCursorStride], n_sure); " + leave("S_early") + " }"),
+    ("						if(early && lane == 0) rel = atomicAdd(&a.cursor[cur], n_sure);", "						if(early && lane == 0) { " + enter("S_early") + " rel = atomicAdd(&a.cursor[cur], n_sure); " + leave("S_early") + " }"),
     ("						while(served < n_dead) // (wave-uniform) the rest: paths that ended unexpectedly, or the home segment has run out\n						{", "						while(served < n_dead) // (wave-uniform) the rest: paths that ended unexpectedly, or the home segment has run out\n						{\n							" + enter("S_fetch_more")),
     ("							served += gn;\n						}", "							served += gn;\n							" + leave("S_fetch_more") + "\n						}"),
     ("			expect = 0u;\n			__builtin_amdgcn_s_sleep(1);", "			" + enter("X_lock_spin") + "\n			expect = 0u;\n			__builtin_amdgcn_s_sleep(1);\n			" + leave("X_lock_spin")),
