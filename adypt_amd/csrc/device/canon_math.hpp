@@ -84,6 +84,13 @@ __device__ __forceinline__ float rcp_ieee(float x)
 }
 __device__ __forceinline__ F3 normalize3(F3 a) { float inv = rcp_ieee(sqrtf(dot3(a, a))); return a * inv; }
 __device__ __forceinline__ F3 reflect3(F3 i, F3 n) { float k = 2.0f * dot3(n, i); return fma3(n, -k, i); }
+// acc |= bits in the lanes where a <= b: the compare writes the lane mask straight into EXEC, the OR runs under it, EXEC comes back — 4.3 + 2.5 issue cycles where
+// v_cmp + v_cndmask + (half a) v_or3 take 10.8; eight of them per node visit
+__device__ __forceinline__ void or_if_le(uint32_t &acc, float a, float b, uint32_t bits)
+{
+	unsigned long long ex;
+	asm volatile("s_mov_b64 %1, exec\n\tv_cmpx_le_f32_e32 vcc, %2, %3\n\tv_or_b32_e32 %0, %0, %4\n\ts_mov_b64 exec, %1" : "+v"(acc), "=&s"(ex) : "v"(a), "v"(b), "v"(bits) : "vcc");
+}
 // GLSL min/max NaN rule
 __device__ __forceinline__ float gl_min(float x, float y) { return y < x ? y : x; }
 __device__ __forceinline__ float gl_max(float x, float y) { return x < y ? y : x; }
