@@ -13,8 +13,8 @@
 //     the slot, slot index onto the workgroup's to-shade list) and takes ready rays off the to-trace list — LDS only, a short spin lock;
 //   * whichever wave finds >= shade_min deposited hits takes 64 of them and runs one bounce of Render() for them with all 64 lanes —
 //     FetchInfo, the illum switch, accumulate on termination: exactly k_shade's work at k_shade's lane occupancy — while the other waves
-//     of the CU keep traversing and hide its gather latency; its own rays wait, the ten registers of their state that cannot be recomputed
-//     from the path table parked in LDS for the round, so that the shading code has the registers (one shading wave per workgroup at a time);
+//     of the CU keep traversing and hide its gather latency; its own rays wait, ten registers of their state (hit, node groups, pending
+//     node, slot and stack pointer) parked in LDS for the round so that the shading code has them (one shading wave per workgroup at a time);
 //   * a path that ends is replaced from the global queue (the bounce-1 rays k_shade_first wrote) by the shading wave itself: one device
 //     atomic per shading round, issued BEFORE the gathers for the paths that are certain to end (miss, last bounce) so that its latency is hidden;
 //   * the hit's triangle record is looked up by REFERENCE index (the traversal's own index: SceneArgs::triangles here is the per-reference copy
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	};
 
 	// The part of the ray setup (traversal.glsl:16-23) that is a function of the path slot alone: origin and direction as the table holds them
-	// while the ray is traced.  Also how a shading wave gets these registers back after a round (they are not parked).
+	// while the ray is traced.
 	auto aim = [&]() {
 		const float ox = __uint_as_float(tab[T_OX * kPathSlots + ray]), oy = __uint_as_float(tab[T_OY * kPathSlots + ray]), oz = __uint_as_float(tab[T_OZ * kPathSlots + ray]);
 		F3 dir = f3(__uint_as_float(tab[T_DX * kPathSlots + ray]), __uint_as_float(tab[T_DY * kPathSlots + ray]), __uint_as_float(tab[T_DZ * kPathSlots + ray]));
@@ -503,7 +503,9 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 						hit_t = __uint_as_float(p0.x); hit_u = __uint_as_float(p0.y); hit_v = __uint_as_float(p0.z); hit_idx = (int32_t)p0.w;
 						ng_x = p1.x; ng_y = p1.y; tg_x = p1.z; tg_y = p1.w;
 						node = p2.x; ray = p2.y & 0xffffu; sp = (int)(p2.y >> 16);
-						aim();
+						// (origin, direction, inverse direction and octant of the wave's own rays stayed in their registers: recomputing them from the table after
+						// every round — 77 vector instructions, a square root and four reciprocals among them — cost 0.9 %; the price is one register pair the
+						// round spills to scratch)
 					}
 					wg_lock(ctl, lane);
 					n_t = uni(ctl->n_trace); h_t = uni(ctl->h_trace);
