@@ -1,7 +1,7 @@
 """Developer tool: copy the bench lines and the shard / primary-rate measurements of a GPU run (gpurun_out/r5/final/, written by the command in
 this file's last lines) into profiles/r5_bench_json_*.json and profiles/r5_primary_rate_and_shard_emulation_1gpu.txt, and print the numbers the
 documents quote.    python tools/finalize_bench_profiles.py [dir]
-GPU side:  O=gpurun_out/r5/final; python bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_command.json; python bench.py > $O/default.json;
+GPU side (tools/full_cycle.sh does all of it):  O=gpurun_out/r5/final; python bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_command.json; python bench.py > $O/default.json;
   ADYPT_FUSED_BOUNCES=0 python bench.py --gpus 1 --steps 20 --warmup 5 --no-hbm-block --no-cpu-baseline > $O/launch_per_bounce.json;
   python bench.py --scene salle --width 4096 --height 4096 --steps 8 --warmup 2 --no-hbm-block --no-cpu-baseline > $O/salle.json;
   for n in 1 2 4 8; do SWEEP_NRANKS=$n python tools/path_sweep.py 1 "-:" "-:ADYPT_FUSED_BOUNCES=0"; done > $O/shard.log;
@@ -11,7 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O = (sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r5", "final")) + "/"
 P = os.path.join(ROOT, "profiles") + "/"
 lines = {}
-for src, dst in (("driver_command", "driver_command"), ("default", "default"), ("launch_per_bounce", "launch_per_bounce"), ("salle", "salle_4096x4096")):
+for src, dst in (("driver_command", "driver_command"), ("default", "default"), ("launch_per_bounce", "launch_per_bounce"), ("salle", "salle_4096x4096"), ("no_deferral", "no_deferral")):
+    if not os.path.exists(O + src + ".json"):
+        continue  # (no_deferral: ADYPT_RARE_MIN=0, written by tools/full_cycle.sh only)
     line = open(O + src + ".json").read().strip().splitlines()[-1]
     lines[src] = json.loads(line)
     open(P + "r5_bench_json_%s.json" % dst, "w").write(line + "\n")
