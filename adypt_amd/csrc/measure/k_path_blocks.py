@@ -20,7 +20,10 @@ SETS = {"trip": ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_p
         "rare": ["trip", "shade", "A_pop_spill", "A_push_spill", "div_slow", "S_fetch_more", "S_early", "X_lock_spin", "exchange", "setup", "F_try", "S_defer"]}
 LANES = os.environ.get("ADYPT_BLOCKS_LANES", "0") != "0"   # 1: the counters add up the ACTIVE LANES at each entry (s_bcnt1 of exec) instead of the entries: five 32-bit counters per pass
 SETS_LANES = {"trip": ["trip", "A_choose", "C_woop", "D_slab", "E_flush"], "shade": ["S_surface", "S_textured", "S_glossy", "S_diffuse", "S_dielectric"],
-              "rare": ["S_miss", "S_mirror", "S_dead", "S_alive", "S_replace"]}
+              "rare": ["S_miss", "S_mirror", "S_dead", "S_alive", "S_replace"],
+              # why lanes sit out a trip's slab test (probe blocks that exist in this pass only): no ray | triangles of the last node left after this trip's pair;
+              # and the triangle pair: lanes with two or more triangles, those whose second goes to the neighbour, neighbours that take one
+              "wait": ["W_idle", "W_wait", "W_two", "W_coop", "W_helper"]}
 NAMES = SETS_LANES[SET] if LANES else SETS[SET]
 # Counters: a value that is modified inside a divergent block cannot live in an SGPR the compiler allocates (the merge after the block is per lane).
 # So k_path is held to 96 SGPRs (amdgpu_num_sgpr) and the counters live in s96 .. s101, touched only by inline assembly: two 16-bit counters per
@@ -75,6 +78,11 @@ TRIP_EDITS = [
     ("				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert", "				" + enter("E_flush") + "\n				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert"),
     ("				active = false;\n			}\n		}", "				active = false;\n				" + leave("E_flush") + "\n			}\n		}"),
 ]
+if LANES and SET == "wait":
+    TRIP_EDITS += [
+        ("			if(tg_y != 0)\n			{\n				" if False else "				// more triangles of this node: next trip (the pending node is fetched in the trip that consumes the last of them)\n", "				" + enter("W_wait") + "\n"),
+        ("			const bool do_test = has_tri || helper;", "			if(!active) { " + enter("W_idle") + " }\n			if(two) { " + enter("W_two") + " }\n			if(coop) { " + enter("W_coop") + " }\n			if(helper) { " + enter("W_helper") + " }\n			const bool do_test = has_tri || helper;"),
+    ]
 edit("traverse_trip.inc", TRIP_EDITS)
 # (fetch_rays' loop over the 8 queue segments is unrolled: 8 equal instances of the block, one counter = tries in all)
 edit("traverse.hpp", [("		if((seg_done >> s) & 1u) continue;\n		const uint32_t seg_len = (uint32_t)__builtin_amdgcn_readlane((int)seg_len_lanes, s);",
