@@ -1,6 +1,6 @@
 """Developer tool (GPU box): random scheduling tunables of k_path (deferred-ring threshold, shading-batch size, refill threshold, workgroups per CU, LDS stack depth,
 frames in flight) on small scenes — every run in its own process under a timeout (a deadlock shows as a timeout, not as a hung box), the image, the primary-hit
-cache and the counters compared bit for bit with the launch-per-bounce pipeline.    python tools/stress_path_tunables.py [n_cases] [seed]"""
+cache and the counters compared bit for bit with the launch-per-bounce pipeline.    python tools/stress_path_tunables.py [n_cases] [seed]      (STRESS_BIG=1: larger frames of the bench scene)"""
 import json, os, random, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -23,12 +23,13 @@ for i in range(n):
            "ADYPT_PATH_BLOCKS_PER_CU": rnd.choice([1, 1, 2, 4, 6])}
     if rnd.random() < 0.3: env["ADYPT_PATH_LDS_DEPTH"] = rnd.choice([1, 2, 3])
     if rnd.random() < 0.3: env["ADYPT_FRAMES_IN_FLIGHT"] = rnd.choice([2, 3, 5])
-    scene = rnd.choice(["tiny0", "tiny0", "sibenik"])
-    w, h = rnd.choice([(64, 40), (120, 68), (200, 120), (320, 200)])
+    big = os.environ.get("STRESS_BIG", "0") != "0"   # the bench scene at up to 960 x 540: workgroups that hold full tables, rounds that defer
+    scene = rnd.choice(["sponza", "sponza", "sibenik"] if big else ["tiny0", "tiny0", "sibenik"])
+    w, h = rnd.choice([(480, 270), (640, 360), (960, 540)] if big else [(64, 40), (120, 68), (200, 120), (320, 200)])
     case = {"scene": scene, "w": w, "h": h, "spp": rnd.choice([5, 8, 12]), "env": env,
             "pt": {"tmpLifetime": rnd.choice([1, 3, 4, 16]), "maxBounce": rnd.choice([2, 5, 8, 13]), "subpixel": rnd.choice([1, 2, 3]), "stackSize": 24}}
     try:
-        r = subprocess.run([sys.executable, "-c", CHILD, json.dumps(case)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=90, cwd=ROOT)
+        r = subprocess.run([sys.executable, "-c", CHILD, json.dumps(case)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, cwd=ROOT)
         ok = r.returncode == 0
         msg = r.stdout.decode().strip().splitlines()[-1:] if ok else r.stderr.decode().strip().splitlines()[-3:]
     except subprocess.TimeoutExpired:
