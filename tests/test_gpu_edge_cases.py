@@ -424,3 +424,50 @@ def test_material_zoo_matches_oracle(env, tmp_path, sobol_matrices, monkeypatch)
     seen = set(np.unique(np.frombuffer(sc.triangles, dtype=np.uint8).reshape(-1, 100)[tri[tri >= 0]][:, 96:100].copy().view(np.int32)))
     assert len(seen) >= len(mats)                    # the camera really sees every patch
     assert np.isfinite(img).all()
+
+
+def test_room_of_glossy_and_glass_fills_the_deferred_ring(tmp_path, sobol_matrices, monkeypatch):
+    """k_path's shading rounds move hits that need the glossy lobe or the dielectric branch to a second ring and shade them in rounds of their own
+    (adypt_amd/csrc/device/path.hpp).  In a closed room whose every surface but the lamp is glossy or glass nearly every hit is one of those: the ring is
+    full most of the time, what does not fit is shaded where it is found, and with one workgroup per CU the workgroups hold full path tables for most
+    of the launch.  Every bit as the oracle computes it, and as the launch-per-bounce pipeline does."""
+    mats = "newmtl gl\nKd 0.5 0.4 0.3\nKs 0.4 0.4 0.4\nNs 120\nillum 2\nnewmtl glass\nKd 1 1 1\nNi 1.45\nillum 7\nnewmtl lamp\nKd 0 0 0\nKe 7 6 5\nillum 1\n"
+    (tmp_path / "room.mtl").write_text(mats)
+    v, f = [], []
+    def quad(a, b, c, d, mat):
+        i = len(v) + 1
+        v.extend([a, b, c, d])
+        f.append("usemtl %s\nf %d %d %d\nf %d %d %d\n" % (mat, i, i + 1, i + 2, i, i + 2, i + 3))
+    X, Y, Z = 6.0, 4.0, 5.0
+    quad((0, 0, 0), (X, 0, 0), (X, 0, Z), (0, 0, Z), "gl"); quad((0, Y, 0), (0, Y, Z), (X, Y, Z), (X, Y, 0), "gl")
+    quad((0, 0, 0), (0, Y, 0), (X, Y, 0), (X, 0, 0), "gl"); quad((0, 0, Z), (X, 0, Z), (X, Y, Z), (0, Y, Z), "gl")
+    quad((0, 0, 0), (0, 0, Z), (0, Y, Z), (0, Y, 0), "glass"); quad((X, 0, 0), (X, Y, 0), (X, Y, Z), (X, 0, Z), "gl")
+    quad((2, Y - 0.01, 2), (4, Y - 0.01, 2), (4, Y - 0.01, 3), (2, Y - 0.01, 3), "lamp")
+    quad((2.5, 0.0, 1.5), (3.5, 0.0, 1.5), (3.5, 1.2, 2.0), (2.5, 1.2, 2.0), "glass")
+    (tmp_path / "room.obj").write_text("mtllib room.mtl\n" + "".join("v %g %g %g\n" % p for p in v) + "".join(f))
+    monkeypatch.setenv("ADYPT_PATH_BLOCKS_PER_CU", "1")
+    w, h = 160, 90
+    sc, b, pt, p = _tracer(str(tmp_path / "room.obj"), w, h)
+    p.max_bounce, p.tmp_lifetime = 8, 4
+    pt.SetConfig(p)
+    ip, iv = api.camera_matrices(60.0, 200.0, -5.0, w, h)
+    pos = [4.5, 2.0, 4.0]
+    pt.SetCamera(ip, iv, pos)
+    osc = O.Scene(b.nodes, b.tri_indices, sc.triangles, sc.materials)
+    P = O.make_params(w, h, pos, ip, iv, stack_size=p.stack_size, max_bounce=p.max_bounce, subpixel=p.subpixel,
+                      tmp_life=p.tmp_lifetime, tmin=p.ray_tmin, clamp=p.clamp, sun=list(p.sun))
+    pt.SetInstrumentation(counters=True)
+    imgs = {}
+    for fused in (True, False):
+        pt.SetFusedBounces(fused)
+        pt.Reset(); pt.ResetStats()
+        pt.Trace(True, 6)
+        imgs[fused] = (pt.ReadResult(), pt.GetStats())
+    st = O.PathTracerState(w, h)
+    ost = O.pt_frames(osc, P, O.shift_bytes(77, w, h), sobol_matrices, st, 6).as_dict()
+    assert imgs[True][1]["path_rays"] > 0 and imgs[False][1]["path_rays"] == 0
+    assert np.array_equal(bits(imgs[True][0]), bits(st.accum[..., :3]))
+    assert np.array_equal(bits(imgs[False][0]), bits(st.accum[..., :3]))
+    assert (imgs[True][1]["rays"], imgs[True][1]["shaded"]) == (ost["rays"], ost["shaded"])
+    assert ost["shaded"] > 5 * w * h   # paths really bounce around in there
+
