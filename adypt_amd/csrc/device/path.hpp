@@ -65,6 +65,7 @@ struct PathArgs {
 	int32_t stack_size, lds_depth;
 	uint32_t refill_min, shade_min;
 	uint32_t rare_min;             // deferred hits (glossy lobe / dielectric) a shading round waits for; 0 = no round defers anything
+	uint32_t defer_max;            // a round defers such hits only when it holds at most this many of them (more: those branches are well occupied where they are)
 	int32_t b0;                    // bounce index of the queue's rays (1: k_shade_first did bounce 0)
 	float tmin;
 };
@@ -410,7 +411,8 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					{
 						const bool rare = have && tri_idx != -1 && !last && __float_as_uint(tc.v[19]) != 0u; // glossy lobe or dielectric (tracer.hip: the record's class word)
 						const unsigned long long rm = __ballot(rare);
-						if(rm != 0ull)
+						// (where most hits are of that kind — a room of glossy walls — moving them only empties this round and overflows the ring: -31 % measured)
+						if(rm != 0ull && (uint32_t)__popcll(rm) <= a.defer_max)
 						{
 							const uint32_t room = (uint32_t)kRareCap - n_r, rr = lane_rank(rm);
 							const bool defer = rare && rr < room;

@@ -182,6 +182,7 @@ struct adypt_ctx {
 	int path_blocks = 0, path_lds_depth = 0; // launch geometry of k_path
 	size_t path_lds = 0;
 	uint32_t shade_min = 64;       // deposited hits a wave of k_path waits for before it shades a batch
+	uint32_t defer_max = 24;       // ... and a round defers them only when it holds at most this many (tunables.hpp)
 	uint32_t rare_min = 48;        // deferred hits (glossy lobe / dielectric) a shading round of k_path waits for; 0 = nothing is deferred
 	int deal_chunks = 1;           // k_gen_primary deals 256-path chunks round-robin to the 8 queue segments (ADYPT_GEN_DEAL=0: one contiguous run each)
 
@@ -407,7 +408,7 @@ int launch_path(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int pari
 	a.spill = pipe.spill; a.stats = c->d_stats;
 	a.seg_cap = win.seg_cap;
 	a.stack_size = c->params.stack_size; a.lds_depth = c->path_lds_depth;
-	a.refill_min = c->refill_min; a.shade_min = c->shade_min; a.rare_min = c->rare_min;
+	a.refill_min = c->refill_min; a.shade_min = c->shade_min; a.rare_min = c->rare_min; a.defer_max = c->defer_max;
 	a.b0 = b0; a.tmin = c->params.ray_tmin;
 	hipEvent_t *stop = begin_timing(c, 2, pipe.stream);
 	const PathKernArgs K{a, f, sc, px, stats ? 1 : 0};
@@ -889,7 +890,7 @@ Tunables read_tunables()
 	t.bite = (int)num("ADYPT_BITE", 1, 4096, 0); t.bite_primary = (int)num("ADYPT_BITE_PRIMARY", 1, 4096, 0);
 	t.chunk = (int)num("ADYPT_CHUNK", 16, 4096, 0); t.endgame = (int)num("ADYPT_ENDGAME", 0, 1024, -1);
 	t.shade_min = (int)num("ADYPT_SHADE_MIN", 1, 64, 0);
-	t.rare_min = (int)num("ADYPT_RARE_MIN", 0, 64, -1);
+	t.rare_min = (int)num("ADYPT_RARE_MIN", 0, 64, -1); t.defer_max = (int)num("ADYPT_DEFER_MAX", 0, 64, -1);
 	t.lds_stack_depth = (int)num("ADYPT_LDS_STACK_DEPTH", 1, kLdsStackMax, 0); t.trace_blocks_per_cu = (int)num("ADYPT_TRACE_BLOCKS_PER_CU", 1, 16, 0);
 	t.path_blocks_per_cu = (int)num("ADYPT_PATH_BLOCKS_PER_CU", 1, 8, 0); t.path_lds_depth = (int)num("ADYPT_PATH_LDS_DEPTH", 1, kLdsStackMax, 0);
 	t.path_verbose = flag("ADYPT_PATH_VERBOSE", 0);
@@ -1001,6 +1002,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		c->audit_selftest = t.audit_selftest; c->single_overlap = t.single_overlap;
 		if(t.shade_min > 0) c->shade_min = (uint32_t)t.shade_min;
 		if(t.rare_min >= 0) c->rare_min = (uint32_t)t.rare_min;
+		if(t.defer_max >= 0) c->defer_max = (uint32_t)t.defer_max;
 		if(t.chunk > 0) c->chunk = (uint32_t)t.chunk;
 		if(t.endgame >= 0) c->endgame = (uint32_t)t.endgame;
 		if(t.bite > 0) c->bite = c->bite_primary = (uint32_t)t.bite;

@@ -17,6 +17,7 @@
 //   ADYPT_ENDGAME                 endgame                0..1024        see traverse.hpp   size of the end-of-launch ray pool
 //   ADYPT_SHADE_MIN               shade_min              1..64          64        deposited hits a k_path wave waits for before shading
 //   ADYPT_RARE_MIN                rare_min               0..64          48        deferred hits (glossy lobe / dielectric) a k_path shading round waits for; 0 = nothing is deferred
+//   ADYPT_DEFER_MAX               defer_max              0..64          24        ... and a round defers them only when it holds at most this many
 //   ADYPT_LDS_STACK_DEPTH         lds_stack_depth        1..kLdsStackMax  auto    LDS part of k_trace's stack (tests: forces the HBM spill path)
 //   ADYPT_TRACE_BLOCKS_PER_CU     trace_blocks_per_cu    1..16          auto      k_trace workgroups per CU
 //   ADYPT_PATH_BLOCKS_PER_CU      path_blocks_per_cu     1..8           6         k_path workgroups per CU
@@ -42,7 +43,7 @@ struct Tunables {
 	int frames_in_flight = 0;       // 0 = automatic
 	int pipeline = 1;
 	int fused_bounces = 1, first_fused = 1, single_fused = 1, single_overlap = 1, gen_deal = 1, shade_bin = 0;
-	int refill_min = 0, refill_min_primary = 0, bite = 0, bite_primary = 0, chunk = 0, endgame = -1, shade_min = 0, rare_min = -1; // 0 (endgame, rare_min: -1) = the built-in default
+	int refill_min = 0, refill_min_primary = 0, bite = 0, bite_primary = 0, chunk = 0, endgame = -1, shade_min = 0, rare_min = -1, defer_max = -1; // 0 (endgame, rare_min, defer_max: -1) = the built-in default
 	int lds_stack_depth = 0, trace_blocks_per_cu = 0, path_blocks_per_cu = 0, path_lds_depth = 0, path_verbose = 0;
 	long ref_triangles_max_mb = -1; // -1 = automatic
 	std::string rccl_lib;

@@ -97,7 +97,7 @@ SHADE_PATH = [
     ("							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135\n							alive = false;",
      "							" + enter("S_miss") + "\n							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135\n							alive = false;\n							" + leave("S_miss")),
     ("							const SurfaceInfo si = fetch_info(f, sc, tc, tri_idx, tu, tv);", "							" + enter("S_surface") + "\n							const SurfaceInfo si = fetch_info(f, sc, tc, tri_idx, tu, tv);"),
-    ("						if(rm != 0ull)\n						{", "						if(rm != 0ull)\n						{\n							" + enter("S_defer")),
+    ("						if(rm != 0ull && (uint32_t)__popcll(rm) <= a.defer_max)\n						{", "						if(rm != 0ull && (uint32_t)__popcll(rm) <= a.defer_max)\n						{\n							" + enter("S_defer")),
     ("							have = have && !defer;\n						}", "							have = have && !defer;\n							" + leave("S_defer") + "\n						}"),
     ("								alive = respond(f, si, rng, b, dir, color, ret);\n							}\n						}", "								alive = respond(f, si, rng, b, dir, color, ret);\n							}\n							" + leave("S_surface") + "\n						}"),
     ("						if(!alive) // main()'s clamp (pathtracer.glsl:224); the running mean is k_resolve's, in frame order (a k_path pass is always batched)\n							f.done[pi] = make_float4(gl_min(ret.x, f.clamp), gl_min(ret.y, f.clamp), gl_min(ret.z, f.clamp), 1.0f);",

@@ -426,7 +426,8 @@ def test_material_zoo_matches_oracle(env, tmp_path, sobol_matrices, monkeypatch)
     assert np.isfinite(img).all()
 
 
-def test_room_of_glossy_and_glass_fills_the_deferred_ring(tmp_path, sobol_matrices, monkeypatch):
+@pytest.mark.parametrize("defer_max", ["64", "24"])   # every such hit of a round is moved (the ring overflows) | the default: rounds full of them keep them
+def test_room_of_glossy_and_glass_fills_the_deferred_ring(defer_max, tmp_path, sobol_matrices, monkeypatch):
     """k_path's shading rounds move hits that need the glossy lobe or the dielectric branch to a second ring and shade them in rounds of their own
     (adypt_amd/csrc/device/path.hpp).  In a closed room whose every surface but the lamp is glossy or glass nearly every hit is one of those: the ring is
     full most of the time, what does not fit is shaded where it is found, and with one workgroup per CU the workgroups hold full path tables for most
@@ -446,6 +447,7 @@ def test_room_of_glossy_and_glass_fills_the_deferred_ring(tmp_path, sobol_matric
     quad((2.5, 0.0, 1.5), (3.5, 0.0, 1.5), (3.5, 1.2, 2.0), (2.5, 1.2, 2.0), "glass")
     (tmp_path / "room.obj").write_text("mtllib room.mtl\n" + "".join("v %g %g %g\n" % p for p in v) + "".join(f))
     monkeypatch.setenv("ADYPT_PATH_BLOCKS_PER_CU", "1")
+    monkeypatch.setenv("ADYPT_DEFER_MAX", defer_max)
     w, h = 160, 90
     sc, b, pt, p = _tracer(str(tmp_path / "room.obj"), w, h)
     p.max_bounce, p.tmp_lifetime = 8, 4

@@ -103,6 +103,8 @@ def test_max_bounce_one_needs_no_launch_at_all(scene_cache):
     {"ADYPT_PATH_BLOCKS_PER_CU": 1, "ADYPT_RARE_MIN": 1},          # every such hit is deferred and shaded in a round of its own
     {"ADYPT_PATH_BLOCKS_PER_CU": 1, "ADYPT_RARE_MIN": 64, "ADYPT_SHADE_MIN": 24, "ADYPT_REFILL_MIN": 5},
     {"ADYPT_RARE_MIN": 7, "ADYPT_SHADE_MIN": 1, "ADYPT_REFILL_MIN": 1},
+    {"ADYPT_PATH_BLOCKS_PER_CU": 1, "ADYPT_DEFER_MAX": 64, "ADYPT_RARE_MIN": 16},   # a round defers however many it finds
+    {"ADYPT_PATH_BLOCKS_PER_CU": 1, "ADYPT_DEFER_MAX": 1},                          # ... only a lone one
 ])
 def test_scheduling_tunables_do_not_change_a_bit(env, scene_cache):
     pt = {"tmpLifetime": 4, "maxBounce": 7, "subpixel": 2, "stackSize": 24}
