@@ -39,6 +39,7 @@ constexpr int kPathSlots = ADYPT_PATH_SLOTS;     // paths a workgroup holds: its
 static_assert(kPathSlots >= kTraceThreads && kPathSlots <= 2 * kTraceThreads && kPathSlots % 32 == 0, "k_path: 256 <= slots <= 512");
 constexpr int kTabFields = 10;                   // path word | direction | throughput | origin (to-trace) or hit (to-shade)
 constexpr int kRareCap = 96;                     // entries of the ring of deferred hits (glossy lobe / dielectric): what does not fit is shaded at once
+static_assert(kRareCap >= 64 && kRareCap % 8 == 0 && kRareCap + 64 <= kTraceThreads, "k_path: the deferred ring holds a round's worth (rare_min <= 64), keeps PathCtl 16-byte aligned behind it, and leaves the to-shade ring a full batch when every path waits");
 constexpr int kParkDwords = 10;                  // per-lane ray state a shading wave parks in LDS for the round (hit, groups, node, slot | stack pointer)
 constexpr uint32_t kPwBounceShift = 26;          // path word in the table: bits 25..0 path id, 30..26 bounce index, 31 radiance parked
 constexpr uint32_t kPwIdMask = (1u << kPwBounceShift) - 1u;
