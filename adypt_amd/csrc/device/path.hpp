@@ -40,7 +40,7 @@ static_assert(kPathSlots >= kTraceThreads && kPathSlots <= 2 * kTraceThreads && 
 constexpr int kTabFields = 10;                   // path word | direction | throughput | origin (to-trace) or hit (to-shade)
 constexpr int kRareCap = 96;                     // entries of the ring of deferred hits (glossy lobe / dielectric): what does not fit is shaded at once
 static_assert(kRareCap >= 64 && kRareCap % 8 == 0 && kRareCap + 64 <= kTraceThreads, "k_path: the deferred ring holds a round's worth (rare_min <= 64), keeps PathCtl 16-byte aligned behind it, and leaves the to-shade ring a full batch when every path waits");
-constexpr int kParkDwords = 10;                  // per-lane ray state a shading wave parks in LDS for the round (hit, groups, node, slot | stack pointer)
+constexpr int kParkDwords = 8;                   // per-lane ray state a shading wave parks in LDS for the round (node and triangle groups | hit distance, node, slot | stack pointer)
 constexpr uint32_t kPwBounceShift = 26;          // path word in the table: bits 25..0 path id, 30..26 bounce index, 31 radiance parked
 constexpr uint32_t kPwIdMask = (1u << kPwBounceShift) - 1u;
 constexpr int64_t kPathMaxPaths = (int64_t)1 << kPwBounceShift; // batches with more paths keep the launch-per-bounce pipeline
@@ -74,7 +74,7 @@ struct PathArgs {
 inline size_t path_lds_bytes(int lds_depth)
 {
 	return (size_t)(kTraceThreads / 64) * (size_t)lds_depth * 64 * sizeof(uint2) + (size_t)kTabFields * kPathSlots * 4 + (size_t)kParkDwords * 64 * 4 + 2 * (size_t)kPathSlots * 2 +
-	       (size_t)kRareCap * 2 + sizeof(PathCtl);
+	       (size_t)kRareCap * 2 + sizeof(PathCtl) + kTripTabBytes;
 }
 
 __device__ __forceinline__ void wg_lock(PathCtl *ctl, int lane)
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	constexpr bool ANY = false;
 	constexpr bool kOverflowPerRay = false;
 	constexpr bool kUniformTmin = true; // every ray of the pass has the pass's tmin
-	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64] | path table [kTabFields][kPathSlots] | parking [kParkDwords][64] | to-shade, to-trace, deferred rings | PathCtl
+	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64] | path table [kTabFields][kPathSlots] | parking [kParkDwords][64] | to-shade, to-trace, deferred rings | PathCtl | triangle hand-out tables
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
 	uint2 *my_stack = lds_stack + (size_t)wave * a.lds_depth * 64 + lane;
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	uint16_t *to_shade = (uint16_t *)(park + kParkDwords * 64), *to_trace = to_shade + kPathSlots;
 	uint16_t *to_rare = to_trace + kPathSlots;
 	PathCtl *ctl = (PathCtl *)(to_rare + kRareCap);
+	uint8_t *const trip_tab = (uint8_t *)(ctl + 1) + wave * 64; // the wave's triangle hand-out table (traverse_trip.inc, section B)
 	const uint32_t total_lanes = gridDim.x * (uint32_t)kTraceThreads;
 	const SpillColumn<true> my_spill(a.spill); // (addressed where it is used: traverse.hpp)
 	const int home = blockIdx.x & (kNumSegments - 1);
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	F3 idir = f3(0, 0, 1);
 	bool nx = false, ny = false, nz = false;
 	uint32_t octinv = 7u;
-	float hit_t = 1e9f, hit_u = 0.0f, hit_v = 0.0f;
-	int32_t hit_idx = -1;
+	float hit_t = 1e9f;
+	int32_t hit_idx = -1; // (STATS only: the hit itself — reference index, u, v — lives in the path's table slot, below)
 	int sp = 0;
 	uint32_t ng_x = 0, ng_y = 0, tg_x = 0, tg_y = 0;
 	uint32_t n_nodes = 0, n_tris = 0, hash = 0, max_depth = 0;
@@ -253,7 +254,10 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 			if(setup)
 			{
 				aim();
-				hit_t = 1e9f; hit_u = 0.0f; hit_v = 0.0f; hit_idx = -1;
+				// The hit of the ray in flight lives in the origin fields of its slot (the origin is in registers from here on): written when a triangle
+				// is accepted (ADYPT_TRIP_TAKE_HIT below), read by the shading round — never held in registers, never parked, nothing to deposit
+				tab[T_OX * kPathSlots + ray] = 0xffffffffu; // no hit (traversal.glsl:30)
+				hit_t = 1e9f; hit_idx = -1;
 				sp = 0;
 				ng_x = 0; ng_y = 0x80000000u; tg_x = 0; tg_y = 0;
 				if(STATS) { n_nodes = 0; n_tris = 0; hash = 0x811c9dc5u; max_depth = 0; }
@@ -286,8 +290,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				// of a SIMD's issue slots (1 / 6) the block's few hundred instructions would keep it away from them several times longer
 				__builtin_amdgcn_s_setprio(ADYPT_PATH_PRIO);
 				asm volatile("; ADYPT_MARK exchange_begin");
-				// deposit, first half (no lock: the slot is this lane's until it is on the list): the hit, by reference index
-				if(flush) { tab[T_OX * kPathSlots + ray] = (uint32_t)hit_idx; tab[T_OY * kPathSlots + ray] = __float_as_uint(hit_u); tab[T_OZ * kPathSlots + ray] = __float_as_uint(hit_v); }
+				// (deposit: the hit, by reference index, is in the slot already)
 				const uint32_t fl_rank = lane_rank(fl), idle_rank = lane_rank(idle);
 				auto ring = [](uint32_t i) { return i >= (uint32_t)kPathSlots ? i - (uint32_t)kPathSlots : i; };
 				wg_lock(ctl, lane);
@@ -348,9 +351,8 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					uint32_t lane_here = (uint32_t)lane;
 					asm volatile("" : "+v"(lane_here));
 					uint32_t *pk_lane = park + lane_here * 4;
-					*(uint4 *)(pk_lane + 0 * 256) = make_uint4(__float_as_uint(hit_t), __float_as_uint(hit_u), __float_as_uint(hit_v), (uint32_t)hit_idx);
-					*(uint4 *)(pk_lane + 1 * 256) = make_uint4(ng_x, ng_y, tg_x, tg_y);
-					*(uint2 *)(park + 2 * 256 + lane_here * 2) = make_uint2(node, ray | ((uint32_t)sp << 16));
+					*(uint4 *)(pk_lane + 0 * 256) = make_uint4(ng_x, ng_y, tg_x, tg_y);
+					*(uint4 *)(pk_lane + 1 * 256) = make_uint4(__float_as_uint(hit_t), node, ray | ((uint32_t)sp << 16), STATS ? (uint32_t)hit_idx : 0u);
 					asm volatile("" ::: "memory");
 					bool have = (uint32_t)lane < take;
 					uint32_t pw = 0;
@@ -502,10 +504,9 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					// the wave's own rays come back: the parked registers, and origin / direction / octant from the table as at the ray's start
 					{
 						const uint4 p0 = *(const uint4 *)(pk_lane + 0 * 256), p1 = *(const uint4 *)(pk_lane + 1 * 256);
-						const uint2 p2 = *(const uint2 *)(park + 2 * 256 + lane_here * 2);
-						hit_t = __uint_as_float(p0.x); hit_u = __uint_as_float(p0.y); hit_v = __uint_as_float(p0.z); hit_idx = (int32_t)p0.w;
-						ng_x = p1.x; ng_y = p1.y; tg_x = p1.z; tg_y = p1.w;
-						node = p2.x; ray = p2.y & 0xffffu; sp = (int)(p2.y >> 16);
+						ng_x = p0.x; ng_y = p0.y; tg_x = p0.z; tg_y = p0.w;
+						hit_t = __uint_as_float(p1.x); node = p1.y; ray = p1.z & 0xffffu; sp = (int)(p1.z >> 16);
+						if(STATS) hit_idx = (int32_t)p1.w;
 						// (origin, direction, inverse direction and octant of the wave's own rays stayed in their registers: recomputing them from the table after
 						// every round — 77 vector instructions, a square root and four reciprocals among them — cost 0.9 %; the price is one register pair the
 						// round spills to scratch)
@@ -538,8 +539,10 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				skip_trip = true;
 			}
 		}
+#define ADYPT_TRIP_TAKE_HIT(u, v, idx) { tab[T_OX * kPathSlots + ray] = (idx); tab[T_OY * kPathSlots + ray] = __float_as_uint(u); tab[T_OZ * kPathSlots + ray] = __float_as_uint(v); if(STATS) hit_idx = (int32_t)(idx); }
 		if(!skip_trip)
 #include "traverse_trip.inc"
+#undef ADYPT_TRIP_TAKE_HIT
 	}
 
 	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------

@@ -350,7 +350,7 @@ int configure_trace(adypt_ctx *c, int stack_size)
 	c->lds_depth = std::max(1, std::min(stack_size, kLdsStackMax));
 	// testing / tuning hook: a smaller LDS part pushes stack entries into the global spill array (tests cover that path)
 	if(c->tun.lds_stack_depth > 0) c->lds_depth = std::max(1, std::min(c->lds_depth, c->tun.lds_stack_depth));
-	size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2) + sizeof(WgPool); // stacks + the workgroup's ray pool
+	size_t lds = (size_t)(kTraceThreads / 64) * c->lds_depth * 64 * sizeof(uint2) + sizeof(WgPool) + kTripTabBytes; // stacks + the workgroup's ray pool + the waves' triangle hand-out tables
 	int per_cu = 0;
 	HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kTraceThreads, lds));
 	c->occupancy_api = per_cu;

@@ -13,9 +13,9 @@
 //     its 5 x 16-byte loads are issued together with the triangle loads of the current node and the latencies
 //     overlap.  The slab test itself still runs after the triangle tests (it needs the shortened hit_t), exactly
 //     like the reference.
-//   * cooperative triangle pair: a lane tests one triangle per trip and hands a second one to its neighbour (lane ^ 1)
-//     when that lane has none of its own (DPP quad swaps of the ray and of the result, no LDS); the owner applies
-//     its own result first, then the neighbour's — the reference's order (section B / C below).
+//   * the wave's triangles are ONE list: a lane offers up to three triangles of its node per trip and lane j of the wave tests
+//     entry j, whoever owns it — rays and verdicts travel through the LDS crossbar (ds_bpermute_b32), the owner applies the
+//     verdicts in the reference's order (traverse_trip.inc, sections B / C).
 //   * the node-group stack lives in LDS, laid out [depth][lane] (ds_write_b64 / ds_read_b64, conflict free); only
 //     entries deeper than kLdsStackMax spill to a global scratch array.  Overflow beyond stackSize is reported.
 //   * XCD-affine queue segments with separate fetch cursors on separate cache lines (see shade.hpp).
@@ -41,6 +41,7 @@ constexpr int kBite = 32;      // default: rays a wave takes from its workgroup'
 constexpr int kEndgame = 4;    // default: the end of a launch = fewer than this many more chunks per wave left in the segment
 struct WgPool { unsigned long long range; uint32_t lock, dry, left, pad; }; // range = (end << 32) | next: reserved, not yet handed to a wave; left: waves that have left the loop (k_trace_camera)
 constexpr int kNodeUint4 = 5;  // the 80-byte WideBVHNode, verbatim (src/BVH/WideBVH.hpp:13-26)
+constexpr size_t kTripTabBytes = (size_t)(kTraceThreads / 64) * 64; // LDS: one byte per lane and wave — which lane owns entry j of the wave's triangle list
 
 // The lane's column of the HBM spill array (stack entries beyond the LDS depth): my_spill[depth x lanes of the launch].  AT_USE: the column's
 // address is computed where it is used, behind a value the compiler cannot hoist — as a pointer it holds two VGPRs through the whole persistent
@@ -151,6 +152,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 	// fewer rays in its segment than one more chunk for every wave, the chunk goes into the pool and the 4 waves take it a.bite rays
 	// at a time (LDS compare-and-swap): the rays a wave can be left holding shrink 4x at the same number of device atomics.
 	WgPool *pool = (WgPool *)(lds_stack + (size_t)(kTraceThreads / 64) * a.lds_depth * 64);
+	uint8_t *const trip_tab = (uint8_t *)(pool + 1) + wave * 64; // the wave's triangle hand-out table (traverse_trip.inc, section B)
 	if(threadIdx.x == 0) { pool->range = 0ull; pool->lock = 0u; pool->dry = 0u; pool->left = 0u; }
 	__syncthreads();
 	// a.endgame more chunks for every wave of the segment (64-bit product: the tuning overrides allow 1024 x 4096 x 1024 waves)
@@ -377,7 +379,9 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 			if(exhausted && loc_next == loc_end) break;
 		}
 		else
+#define ADYPT_TRIP_TAKE_HIT(u, v, idx) { hit_u = (u); hit_v = (v); hit_idx = (int32_t)(idx); }
 #include "traverse_trip.inc"
+#undef ADYPT_TRIP_TAKE_HIT
 	}
 
 	if(flush) // rays finished after the queue ran dry

@@ -22,8 +22,8 @@ LANES = os.environ.get("ADYPT_BLOCKS_LANES", "0") != "0"   # 1: the counters add
 SETS_LANES = {"trip": ["trip", "A_choose", "C_woop", "D_slab", "E_flush"], "shade": ["S_surface", "S_textured", "S_glossy", "S_diffuse", "S_dielectric"],
               "rare": ["S_miss", "S_mirror", "S_dead", "S_alive", "S_replace"],
               # why lanes sit out a trip's slab test (probe blocks that exist in this pass only): no ray | triangles of the last node left after this trip's pair;
-              # and the triangle pair: lanes with two or more triangles, those whose second goes to the neighbour, neighbours that take one
-              "wait": ["W_idle", "W_wait", "W_two", "W_coop", "W_helper"]}
+              # and the triangle list: lanes with two or more, three or more, four or more triangles at hand
+              "wait": ["W_idle", "W_wait", "W_two", "W_three", "W_four"]}
 NAMES = SETS_LANES[SET] if LANES else SETS[SET]
 # Counters: a value that is modified inside a divergent block cannot live in an SGPR the compiler allocates (the merge after the block is per lane).
 # So k_path is held to 96 SGPRs (amdgpu_num_sgpr) and the counters live in s96 .. s101, touched only by inline assembly: two 16-bit counters per
@@ -55,7 +55,7 @@ def leave(n):
 
 TRIP_EDITS = [
     ("			const bool can_pop = !pending && ng_y <= 0x00ffffffu && sp != 0;", "			asm volatile(\"; ADYPT_MARK sec_A\");\n			const bool can_pop = !pending && ng_y <= 0x00ffffffu && sp != 0;"),
-    ("			auto swap1 = [](uint32_t v)", "			asm volatile(\"; ADYPT_MARK sec_B\");\n			auto swap1 = [](uint32_t v)"),
+    ("			auto pull = [](uint32_t lane4, uint32_t v)", "			asm volatile(\"; ADYPT_MARK sec_B\");\n			auto pull = [](uint32_t lane4, uint32_t v)"),
     ("			float tt, tu, tv;\n", "			asm volatile(\"; ADYPT_MARK sec_C\");\n			float tt, tu, tv;\n"),
     ("			if(tg_y != 0)\n			{\n				// more triangles of this node", "			asm volatile(\"; ADYPT_MARK sec_D\");\n			if(tg_y != 0)\n			{\n				// more triangles of this node"),
     ("			if(active && tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))", "			asm volatile(\"; ADYPT_MARK sec_E\");\n			if(active && tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))"),
@@ -81,7 +81,7 @@ TRIP_EDITS = [
 if LANES and SET == "wait":
     TRIP_EDITS += [
         ("			if(tg_y != 0)\n			{\n				" if False else "				// more triangles of this node: next trip (the pending node is fetched in the trip that consumes the last of them)\n", "				" + enter("W_wait") + "\n"),
-        ("			const bool do_test = has_tri || helper;", "			if(!active) { " + enter("W_idle") + " }\n			if(two) { " + enter("W_two") + " }\n			if(coop) { " + enter("W_coop") + " }\n			if(helper) { " + enter("W_helper") + " }\n			const bool do_test = has_tri || helper;"),
+        ("			const bool do_test = (uint32_t)lane < n_tests;", "			if(!active) { " + enter("W_idle") + " }\n			if(tg1 != 0) { " + enter("W_two") + " }\n			if(tg2 != 0) { " + enter("W_three") + " }\n			if(tg3 != 0) { " + enter("W_four") + " }\n			const bool do_test = (uint32_t)lane < n_tests;"),
     ]
 edit("traverse_trip.inc", TRIP_EDITS)
 # (fetch_rays' loop over the 8 queue segments is unrolled: 8 equal instances of the block, one counter = tries in all)

@@ -16,7 +16,7 @@ SETS = {"trip": ["setup", "exchange", "shade", "trip", "A_pop", "A_choose", "A_p
         "rare": ["trip", "shade", "A_pop_spill", "A_push_spill", "div_slow", "S_fetch_more", "S_early", "X_lock_spin", "exchange", "setup", "F_try", "S_defer"]}  # = adypt_amd/csrc/measure/k_path_blocks.py
 LANES = os.environ.get("ADYPT_BLOCKS_LANES", "0") != "0"  # the variant was built with ADYPT_BLOCKS_LANES=1: the counters hold active lanes, five per pass
 SETS_LANES = {"trip": ["trip", "A_choose", "C_woop", "D_slab", "E_flush"], "shade": ["S_surface", "S_textured", "S_glossy", "S_diffuse", "S_dielectric"],
-              "rare": ["S_miss", "S_mirror", "S_dead", "S_alive", "S_replace"], "wait": ["W_idle", "W_wait", "W_two", "W_coop", "W_helper"]}
+              "rare": ["S_miss", "S_mirror", "S_dead", "S_alive", "S_replace"], "wait": ["W_idle", "W_wait", "W_two", "W_three", "W_four"]}
 NAMES = SETS_LANES[SET] if LANES else SETS[SET]
 scene = os.environ.get("SWEEP_SCENE", "sponza"); fr = int(os.environ.get("SWEEP_FRAMES", "20")); warm = int(os.environ.get("SWEEP_WARMUP", "5"))
 spec = scenes.make_scene(scene, os.environ.get("ADYPT_CACHE", "/tmp/adypt_cache"), width=1920, height=1080,
