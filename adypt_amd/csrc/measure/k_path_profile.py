@@ -33,14 +33,12 @@ rep("""				wg_lock(ctl, lane);
 				wg_lock(ctl, lane);
 				pf_lock += __builtin_readcyclecounter() - l0; }
 				uint32_t n_s = uni(ctl->n_shade)""")
-rep("""				uint32_t take = 0, sslot = 0;
-				if(do_shade)
-				{
-""", """				uint32_t take = 0, sslot = 0;
-				if(!do_shade && n_s >= thr && n_s != 0u) pf_busy += 1; // would have shaded, but another wave of the workgroup is
-				pf_backlog += n_s;
-				if(do_shade)
-				{
+rep("""				const uint32_t take = take_r + take_s;
+				const bool do_shade = take != 0u;
+""", """				const uint32_t take = take_r + take_s;
+				const bool do_shade = take != 0u;
+				if(!do_shade && (bw & 1u) != 0u && n_s + n_r >= thr && n_s + n_r != 0u) pf_busy += 1; // would have shaded, but another wave of the workgroup is
+				pf_backlog += n_s + n_r;
 """)
 rep("""				if(do_shade)
 				{
@@ -77,12 +75,14 @@ rep("""	const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 =
 """)
 rep("""		if(!skip_trip)
 #include "traverse_trip.inc"
+#undef ADYPT_TRIP_TAKE_HIT
 	}
 """, """		if(!skip_trip)
 		{
 		pf_trips += 1; pf_trip_lanes += (uint32_t)__popcll(live);
 #include "traverse_trip.inc"
 		}
+#undef ADYPT_TRIP_TAKE_HIT
 	}
 	if(lane == 0)
 	{
