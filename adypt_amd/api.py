@@ -298,6 +298,19 @@ def camera_matrices(fov: float, yaw: float, pitch: float, width: int, height: in
     return ip, iv
 
 
+def device_free_bytes(device: int) -> Optional[int]:
+    """Free memory of HIP device `device` (hipMemGetInfo through the runtime libadypt_hip.so is linked against), None when the runtime does not answer.
+    Measurement scripts only (bench.py's self-check asks before it creates a second context of a large scene); the library itself never asks."""
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        if hip.hipSetDevice(C.c_int(device)) != 0 or hip.hipMemGetInfo(C.byref(free), C.byref(total)) != 0:
+            return None
+        return int(free.value)
+    except OSError:
+        return None
+
+
 class HipScene:
     """OglScene: the flat arrays the kernels consume.  Initialize(scene, bvh) only records host arrays; the upload
     to HBM happens in HipPathTracer.Initialize (adypt_create) because the C-ABI creates scene + images together."""

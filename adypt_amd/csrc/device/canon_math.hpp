@@ -84,12 +84,17 @@ __device__ __forceinline__ float rcp_ieee(float x)
 }
 __device__ __forceinline__ F3 normalize3(F3 a) { float inv = rcp_ieee(sqrtf(dot3(a, a))); return a * inv; }
 __device__ __forceinline__ F3 reflect3(F3 i, F3 n) { float k = 2.0f * dot3(n, i); return fma3(n, -k, i); }
+// (the helpers below that rewrite EXEC or use SDWA encodings — or_if_le, exp_byte, shl_bytes, traverse_trip.inc's acceptance steps — are GFX9-family wave64 code: v_cmpx writes
+// VCC and EXEC, a lane mask is 64 bits, SDWA exists.  The Makefile's ARCH / HIPFLAGS overrides cannot turn this file into something else silently.)
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__))
+#error "canon_math.hpp: the EXEC-writing and SDWA helpers are written for GFX9-family (CDNA) wave64 targets"
+#endif
 // acc |= bits in the lanes where a <= b: the compare writes the lane mask straight into EXEC, the OR runs under it, EXEC comes back — 4.3 + 2.5 issue cycles where
 // v_cmp + v_cndmask + (half a) v_or3 take 10.8; eight of them per node visit
 __device__ __forceinline__ void or_if_le(uint32_t &acc, float a, float b, uint32_t bits)
 {
 	unsigned long long ex;
-	asm volatile("s_mov_b64 %1, exec\n\tv_cmpx_le_f32_e32 vcc, %2, %3\n\tv_or_b32_e32 %0, %0, %4\n\ts_mov_b64 exec, %1" : "+v"(acc), "=&s"(ex) : "v"(a), "v"(b), "v"(bits) : "vcc");
+	asm volatile("s_mov_b64 %1, exec\n\tv_cmpx_le_f32_e32 vcc, %2, %3\n\tv_or_b32_e32 %0, %0, %4\n\ts_mov_b64 exec, %1" : "+v"(acc), "=&s"(ex) : "v"(a), "v"(b), "v"(bits) : "vcc"); // (EXEC is back before the statement ends; as a clobber the compiler rejects it: a reserved register)
 }
 // GLSL min/max NaN rule
 __device__ __forceinline__ float gl_min(float x, float y) { return y < x ? y : x; }

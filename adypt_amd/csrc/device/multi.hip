@@ -125,6 +125,7 @@ struct Comm {
 	float *rgb = nullptr;            // root only: assembled W*H*3
 	double *scratch = nullptr;       // all-reduce staging (device)
 	static constexpr int kScratch = 64;
+	const Tunables tun = read_tunables(); // read once, when the communicator is made (tunables.hpp)
 };
 
 void free_comm(void *p)
@@ -586,7 +587,10 @@ int adypt_comm_gather_radiance(adypt_ctx *ctx, void **rgb_device)
 		if(r != ADYPT_OK) return r;
 	}
 	HIP_OK(ctx, hipSetDevice(i.device));
-	const Tunables tun = read_tunables();
+	const Tunables &tun = k->tun;
+	// What the watchdog times is the collective and its drain — not the frames a caller has queued in front of it with adypt_trace_spp_async, nor the skew
+	// between ranks that are still rendering: this rank's own stream is drained first (rendering cannot hang on another rank: it has no collective).
+	if(i.nranks > 1) { int r = adypt_wait(ctx); if(r != ADYPT_OK) return r; }
 	GatherWatchdog wd(i.nranks > 1 ? tun.gather_timeout_s : 0.0, [i] {
 		return "[adypt]   rank " + std::to_string(i.rank) + " of " + std::to_string(i.nranks) + " (device " + std::to_string(i.device) + ", " + std::to_string(i.n_local_px) + " local pixels): stream " +
 			   stream_state(i.device, i.stream) + "\n";

@@ -25,6 +25,9 @@
 //     dielectric branch are needed by a few lanes of almost every round: a round that finds such hits among the 64 it took DEFERS them to a second
 //     small ring (the class is a flag in the triangle record, known when the record arrives) and shades the others without those branches; when the
 //     ring holds rare_min of them a round takes them together.  A grouping of the work only: every path is shaded by the same arithmetic;
+//   * the optional sun-visibility query (pathtracer.glsl:132, commented out in the reference) stays inside the launch: a path that hits nothing keeps
+//     its slot and its origin, takes the sun direction and the bounce index kPwShadow, and is traced once more — ending at its first accepted triangle
+//     (traversal.glsl:257-494 per lane: the SUN variant of the kernel) — before the round that finds it again adds the sun term, or not;
 //   * no inter-workgroup communication of any kind, so none of the cross-XCD visibility questions of a streaming queue.
 // The kernel ends when the global queue is dry and every workgroup has finished the paths it holds.
 #pragma once
@@ -41,7 +44,9 @@ constexpr int kTabFields = 10;                   // path word | direction | thro
 constexpr int kRareCap = 96;                     // entries of the ring of deferred hits (glossy lobe / dielectric): what does not fit is shaded at once
 static_assert(kRareCap >= 64 && kRareCap % 8 == 0 && kRareCap + 64 <= kTraceThreads, "k_path: the deferred ring holds a round's worth (rare_min <= 64), keeps PathCtl 16-byte aligned behind it, and leaves the to-shade ring a full batch when every path waits");
 constexpr int kParkDwords = 8;                   // per-lane ray state a shading wave parks in LDS for the round (node and triangle groups | hit distance, node, slot | stack pointer)
-constexpr uint32_t kPwBounceShift = 26;          // path word in the table: bits 25..0 path id, 30..26 bounce index, 31 radiance parked
+constexpr uint32_t kPwBounceShift = 26;          // path word in the table: bits 25..0 path id, 30..26 bounce index (kPwShadow: the ray is the path's sun-visibility query), 31 radiance parked
+constexpr uint32_t kPwShadow = 31;               // (so the query needs max_bounce <= 31: tracer.hip keeps the launch-per-bounce pipeline otherwise)
+constexpr uint32_t kRingMiss = 0x8000u;          // to-shade ring entry: the slot's ray hit nothing (its origin fields still hold the origin)
 constexpr uint32_t kPwIdMask = (1u << kPwBounceShift) - 1u;
 constexpr int64_t kPathMaxPaths = (int64_t)1 << kPwBounceShift; // batches with more paths keep the launch-per-bounce pipeline
 enum { T_PW = 0, T_DX, T_DY, T_DZ, T_CX, T_CY, T_CZ, T_OX, T_OY, T_OZ };
@@ -113,7 +118,7 @@ __device__ __forceinline__ const PathKernArgs &rare_args()
 	return *(const PathKernArgs *)(const __attribute__((address_space(4))) PathKernArgs *)k;
 }
 
-template <bool STATS>
+template <bool STATS, bool SUN>
 __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathKernArgs K)
 {
 	// The kernel's arguments are read in two ways.  What the traversal loop and the prologue need comes from the by-value parameter (the compiler
@@ -124,6 +129,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	constexpr bool ANY = false;
 	constexpr bool kOverflowPerRay = false;
 	constexpr bool kUniformTmin = true; // every ray of the pass has the pass's tmin
+	constexpr bool kTripShadowRays = SUN; // sun-visibility queries among the rays: they end at their first accepted triangle
 	extern __shared__ uint2 lds_stack[]; // [waves][lds_depth][64] | path table [kTabFields][kPathSlots] | parking [kParkDwords][64] | to-shade, to-trace, deferred rings | PathCtl | triangle hand-out tables
 	const int lane = threadIdx.x & 63;
 	const int wave = threadIdx.x >> 6;
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 		const float4 d4 = a.in_d[idx];
 		const F3 c3 = ld3(a.in_col, idx);
 		const uint32_t w = __float_as_uint(d4.w); // path word of the queue: bits 30..0 path id (< 2^26 here), bit 31 radiance parked
-		tab[T_PW * kPathSlots + slot] = (w & (kPathParked | kPwIdMask)) | ((uint32_t)a.b0 << kPwBounceShift);
+		tab[T_PW * kPathSlots + slot] = (w & (kPathParked | kPwIdMask)) | ((SUN && (w & kPathShadow) ? kPwShadow : (uint32_t)a.b0) << kPwBounceShift);
 		tab[T_DX * kPathSlots + slot] = __float_as_uint(d4.x); tab[T_DY * kPathSlots + slot] = __float_as_uint(d4.y); tab[T_DZ * kPathSlots + slot] = __float_as_uint(d4.z);
 		tab[T_CX * kPathSlots + slot] = __float_as_uint(c3.x); tab[T_CY * kPathSlots + slot] = __float_as_uint(c3.y); tab[T_CZ * kPathSlots + slot] = __float_as_uint(c3.z);
 		tab[T_OX * kPathSlots + slot] = __float_as_uint(o.x); tab[T_OY * kPathSlots + slot] = __float_as_uint(o.y); tab[T_OZ * kPathSlots + slot] = __float_as_uint(o.z);
@@ -208,6 +214,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	unsigned long long st_nodes = 0, st_tris = 0, st_hits = 0;
 	uint32_t st_maxdepth = 0;
 	bool any_overflow = false;
+	bool shadow = false; // SUN: the lane's ray is a sun-visibility query
 	uint32_t wave_rays = 0, wave_shaded = 0, wave_bad = 0; // wave-uniform totals, added up per workgroup at the end
 	unsigned long long wp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	auto wave_event = [&](int slot) {
@@ -255,8 +262,9 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 			{
 				aim();
 				// The hit of the ray in flight lives in the origin fields of its slot (the origin is in registers from here on): written when a triangle
-				// is accepted (ADYPT_TRIP_TAKE_HIT below), read by the shading round — never held in registers, never parked, nothing to deposit
-				tab[T_OX * kPathSlots + ray] = 0xffffffffu; // no hit (traversal.glsl:30)
+				// is accepted (ADYPT_TRIP_TAKE_HIT below), read by the shading round — never held in registers, never parked, nothing to deposit.  "No hit"
+				// (traversal.glsl:30) is hit_t still at its start value when the ray is deposited: a bit of the ring entry, and the fields keep the origin
+				if(SUN) shadow = ((tab[T_PW * kPathSlots + ray] >> kPwBounceShift) & 31u) == kPwShadow;
 				hit_t = 1e9f; hit_idx = -1;
 				sp = 0;
 				ng_x = 0; ng_y = 0x80000000u; tg_x = 0; tg_y = 0;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				wg_lock(ctl, lane);
 				uint32_t n_s = uni(ctl->n_shade), h_s = uni(ctl->h_shade), n_t = uni(ctl->n_trace), h_t = uni(ctl->h_trace);
 				const uint32_t lv = uni(ctl->live);
-				if(flush) to_shade[ring(h_s + n_s + fl_rank)] = (uint16_t)ray;
+				if(flush) to_shade[ring(h_s + n_s + fl_rank)] = (uint16_t)(ray | (hit_t == 1e9f ? kRingMiss : 0u)); // (an accepted triangle is nearer than the start value)
 				n_s += n_flush;
 				flush = false;
 				const uint32_t thr = min(a.shade_min, max(1u, lv >> 2)); // fewer than 4 batches of paths left: smaller batches, down to single paths
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				uint32_t sslot = 0;
 				if(do_shade)
 				{
-					if((uint32_t)lane < take_r) sslot = to_rare[ring_r(h_r + (uint32_t)lane)];
+					if((uint32_t)lane < take_r) sslot = to_rare[ring_r(h_r + (uint32_t)lane)]; // (deferred hits: never a miss)
 					else if((uint32_t)lane < take) sslot = to_shade[ring(h_s + (uint32_t)lane - take_r)];
 					h_s = ring(h_s + take_s); n_s -= take_s;
 					h_r = ring_r(h_r + take_r); n_r -= take_r;
@@ -355,6 +363,8 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					*(uint4 *)(pk_lane + 1 * 256) = make_uint4(__float_as_uint(hit_t), node, ray | ((uint32_t)sp << 16), STATS ? (uint32_t)hit_idx : 0u);
 					asm volatile("" ::: "memory");
 					bool have = (uint32_t)lane < take;
+					const bool miss = (sslot & kRingMiss) != 0u;
+					sslot &= kRingMiss - 1u;
 					uint32_t pw = 0;
 					F3 dir = f3(0, 0, 1), color = f3(0, 0, 0), origin = f3(0, 0, 0), ret = f3(0, 0, 0), ret_in = f3(0, 0, 0);
 					int32_t tri_idx = -1;
@@ -364,12 +374,15 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 						pw = tab[T_PW * kPathSlots + sslot];
 						dir = f3(__uint_as_float(tab[T_DX * kPathSlots + sslot]), __uint_as_float(tab[T_DY * kPathSlots + sslot]), __uint_as_float(tab[T_DZ * kPathSlots + sslot]));
 						color = f3(__uint_as_float(tab[T_CX * kPathSlots + sslot]), __uint_as_float(tab[T_CY * kPathSlots + sslot]), __uint_as_float(tab[T_CZ * kPathSlots + sslot]));
-						tri_idx = (int32_t)tab[T_OX * kPathSlots + sslot]; tu = __uint_as_float(tab[T_OY * kPathSlots + sslot]); tv = __uint_as_float(tab[T_OZ * kPathSlots + sslot]);
+						if(!miss) { tri_idx = (int32_t)tab[T_OX * kPathSlots + sslot]; tu = __uint_as_float(tab[T_OY * kPathSlots + sslot]); tv = __uint_as_float(tab[T_OZ * kPathSlots + sslot]); }
 					}
 					const int b = (int)((pw >> kPwBounceShift) & 31u);
 					const int pi = (int)(pw & kPwIdMask);
 					bool parked = (pw & kPathParked) != 0u;
 					const bool last = b + 1 >= f.max_bounce; // the path ends with this iteration whatever it hits: respond() stops after the emission (the switch's outputs have no reader)
+					// SUN: what came back is the path's sun-visibility query (it ends the path either way: `last` holds, kPwShadow + 1 >= max_bounce) | the path escapes
+					// and its query is still to be traced (it keeps its slot)
+					const bool query_back = SUN && (uint32_t)b == kPwShadow, query_next = SUN && f.sun_query != 0 && !query_back && have && tri_idx == -1;
 					// Everything a round waits for that does not depend on another fetch is issued up front, back to back — the hit's triangle record, the
 					// reservation of the paths that replace those certain to end here (miss, or last bounce), the radiance parked so far, the pixel's shift
 					// bytes and the frame's Sobol point of this bounce — and lands behind ONE wait; the material and the texels follow (two more).  A shading
@@ -380,13 +393,13 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					TriCore tc;
 #pragma unroll
 					for(int i = 0; i < 20; ++i) asm volatile("" : "=v"(tc.v[i]));
-					if(have && tri_idx != -1)
+					if(have && tri_idx != -1 && !query_back)
 					{
 						if(a.tri_remap) tri_idx = a.tri_remap[tri_idx]; // (contexts without the per-reference copy of the triangle records)
 						tc = load_tri_core(sc, tri_idx);
 					}
 					// (a path certain to end is never deferred — on its last bounce it does not run the illum switch at all — so the count below holds after the deferral)
-					const bool sure = have && (tri_idx == -1 || last);
+					const bool sure = have && !query_next && (tri_idx == -1 || last); // (an escaped path whose query is still to be traced stays)
 					const uint32_t n_sure = (uint32_t)__popcll(__ballot(sure));
 					const bool early = n_sure != 0u && !((seg_done >> home) & 1u);
 					uint32_t rel;
@@ -430,11 +443,19 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 					{
 						if(parked) ret = f3(r4.x, r4.y, r4.z);
 						ret_in = ret;
-						if(tri_idx == -1)
+						if(query_next)
 						{
-							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135
+							// pathtracer.glsl:132 with the occlusion query enabled: from the position the path escapes from (its slot's origin fields: nothing
+							// was accepted, so nothing overwrote them) towards the sun; throughput and radiance wait in the slot
+							dir = f3(f.sun_query_dir[0], f.sun_query_dir[1], f.sun_query_dir[2]);
+							origin = f3(__uint_as_float(tab[T_OX * kPathSlots + sslot]), __uint_as_float(tab[T_OY * kPathSlots + sslot]), __uint_as_float(tab[T_OZ * kPathSlots + sslot]));
+						}
+						else if(tri_idx == -1)
+						{
+							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135 (a query that came back empty: the sun is visible)
 							alive = false;
 						}
+						else if(query_back) alive = false; // the query hit something: no sun term
 						else
 						{
 							const SurfaceInfo si = fetch_info(f, sc, tc, tri_idx, tu, tv);
@@ -460,7 +481,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 							f.done[pi] = make_float4(ret.x, ret.y, ret.z, 0.0f); // radiance picked up on the way: parked per path (shade.hpp)
 							parked = true;
 						}
-						tab[T_PW * kPathSlots + sslot] = (uint32_t)pi | ((uint32_t)(b + 1) << kPwBounceShift) | (parked ? kPathParked : 0u);
+						tab[T_PW * kPathSlots + sslot] = (uint32_t)pi | ((query_next ? kPwShadow : (uint32_t)(b + 1)) << kPwBounceShift) | (parked ? kPathParked : 0u);
 						tab[T_DX * kPathSlots + sslot] = __float_as_uint(dir.x); tab[T_DY * kPathSlots + sslot] = __float_as_uint(dir.y); tab[T_DZ * kPathSlots + sslot] = __float_as_uint(dir.z);
 						tab[T_CX * kPathSlots + sslot] = __float_as_uint(color.x); tab[T_CY * kPathSlots + sslot] = __float_as_uint(color.y); tab[T_CZ * kPathSlots + sslot] = __float_as_uint(color.z);
 						tab[T_OX * kPathSlots + sslot] = __float_as_uint(origin.x); tab[T_OY * kPathSlots + sslot] = __float_as_uint(origin.y); tab[T_OZ * kPathSlots + sslot] = __float_as_uint(origin.z);
@@ -539,10 +560,12 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 				skip_trip = true;
 			}
 		}
+#define ADYPT_TRIP_SHADOW shadow
 #define ADYPT_TRIP_TAKE_HIT(u, v, idx) { tab[T_OX * kPathSlots + ray] = (idx); tab[T_OY * kPathSlots + ray] = __float_as_uint(u); tab[T_OZ * kPathSlots + ray] = __float_as_uint(v); if(STATS) hit_idx = (int32_t)(idx); }
 		if(!skip_trip)
 #include "traverse_trip.inc"
 #undef ADYPT_TRIP_TAKE_HIT
+#undef ADYPT_TRIP_SHADOW
 	}
 
 	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------

@@ -42,6 +42,7 @@ constexpr int kTriFloat4 = 8;                  // device triangle record: 8 x fl
 constexpr int kMatFloat4 = 5;                  // device material record: the reference's 64 bytes + (texel offset, w, h, 0) of its diffuse texture
 constexpr uint32_t kPathParked = 0x80000000u;  // path word: the path's radiance so far is parked in FrameArgs::done[path id]
 constexpr uint32_t kPathIdMask = 0x7fffffffu;
+constexpr uint32_t kPathShadow = 0x40000000u;  // path word of the queue k_path reads (ids < 2^26 there): the ray is a path's sun-visibility query (pathtracer.glsl:132), not a bounce
 
 struct DeviceStats {                           // accumulated until adypt_reset_stats
 	unsigned long long rays, nodes, tris, hits, shaded, overflows, bad_materials;
@@ -87,6 +88,8 @@ struct FrameArgs {
 	float4 *done;                  // device: [frame in batch][local pixel] finished sample radiance (batches of > 1 frame only)
 	int32_t width, height;
 	int32_t spp, subpixel, tmp_life, max_bounce; // spp = index of the FIRST frame of the batch
+	float sun_query_dir[3];        // sun_query: the (normalised) direction of the occlusion query the reference has commented out (pathtracer.glsl:132)
+	int32_t sun_query;             // 1: the one-launch pipeline traces that query for every escaped path (k_shade_first emits it for bounce 0, k_path for the others)
 	int32_t n_frames;              // frames of this pass (queue position = frame ordinal * n_local_px + local pixel)
 	int32_t frame_first, frame_stride; // batch frame of ordinal r = frame_first + r * frame_stride (a sub-batch of the main pass:
 	                               //   its first frame, 1; the primary-only pass runs just the re-tracing frames: first one, tmp_life)
@@ -642,7 +645,8 @@ __global__ __launch_bounds__(kShadeThreads, 7) void k_shade(FrameArgs f, SceneAr
 // FetchInfo: the surface is fetched ONCE per pixel and group, and per frame only the material response runs — instead of k_gen_primary
 // writing a ray and a hit per path and k_shade reading them back and gathering the same triangle, material and texels 16 times.
 // Same arithmetic per path as k_gen_primary + k_shade(b = 0) (fetch_info / respond are the very functions k_shade calls); which segment a
-// path lands in is scheduling only.  Not used with the sun-visibility query on (escaped paths need their own queue there).
+// path lands in is scheduling only.  With the sun-visibility query on (FrameArgs::sun_query) a path that escapes at bounce 0 is not finished here: its query ray
+// (camera origin -> sun direction, throughput 1) goes into the queue, flagged kPathShadow, and k_path traces it and adds the sun term if nothing is hit.
 __global__ __launch_bounds__(kShadeThreads, 6) void k_shade_first(FrameArgs f, SceneArgs sc, QueueArgs q, PixelArgs px, int count_stats)
 {
 	const uint32_t L = blockIdx.x * kShadeThreads + threadIdx.x;      // local pixel; a workgroup = four 8x8 tiles
@@ -679,11 +683,12 @@ __global__ __launch_bounds__(kShadeThreads, 6) void k_shade_first(FrameArgs f, S
 			}
 		}
 		const int pi = frame * f.n_local_px + (int)L;
-		bool alive = valid;
+		bool alive = valid, query = false;
 		F3 dir = cam_dir, color = f3(1.0f, 1.0f, 1.0f), ret = f3(0, 0, 0);
 		if(valid)
 		{
-			if(!hit) { ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); alive = false; }
+			if(!hit && f.sun_query) { query = true; dir = f3(f.sun_query_dir[0], f.sun_query_dir[1], f.sun_query_dir[2]); }
+			else if(!hit) { ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); alive = false; }
 			else if(si.bad_mat) { alive = false; ++n_bad; }
 			else
 			{
@@ -699,14 +704,15 @@ __global__ __launch_bounds__(kShadeThreads, 6) void k_shade_first(FrameArgs f, S
 		const uint32_t slot = append_slot(alive, q.count_out + seg * kCursorStride, seg * q.seg_cap);
 		if(alive)
 		{
-			st3(q.out_o, slot, si.origin.x, si.origin.y, si.origin.z);
+			if(query) st3(q.out_o, slot, f.origin[0], f.origin[1], f.origin[2]); // (the position the path escapes from: the camera)
+			else st3(q.out_o, slot, si.origin.x, si.origin.y, si.origin.z);
 			bool parked = false;
 			if(__float_as_uint(ret.x) != 0u || __float_as_uint(ret.y) != 0u || __float_as_uint(ret.z) != 0u)
 			{
 				f.done[pi] = make_float4(ret.x, ret.y, ret.z, 0.0f);
 				parked = true;
 			}
-			q.out_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)pi | (parked ? kPathParked : 0u)));
+			q.out_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)pi | (parked ? kPathParked : 0u) | (query ? kPathShadow : 0u)));
 			st3(q.out_col, slot, color.x, color.y, color.z);
 		}
 	}

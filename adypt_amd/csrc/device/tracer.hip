@@ -379,18 +379,24 @@ int configure_trace(adypt_ctx *c, int stack_size)
 		{
 			// LDS is handed out in granules; the occupancy query does not know: measured, it answers 6 for 26944 bytes per workgroup, of which a
 			// compute unit then runs 5 at a time (the sixth of every six waits for a slot: -5 %).  So the budget is whole KiB of (LDS per CU) / want.
-			const size_t budget = std::min<size_t>(((c->lds_per_cu / 1024) / (size_t)want) * 1024, 64 * 1024);
+			// ... of (LDS per CU - 2 KiB) / want: measured (round 6, tools/sweep_env.py), 5 workgroups of 32384 bytes = 161920 of the CU's 163840 do NOT run together — the
+			// "5 per CU" of rounds 4-5 ran 4 (the rate of ADYPT_PATH_BLOCKS_PER_CU=4 to the percent) — while 5 of 30336 do
+			const size_t budget = std::min<size_t>((((c->lds_per_cu - 2048) / 1024) / (size_t)want) * 1024, 64 * 1024);
 			if(budget < fixed + per_entry) continue;
 			int d = (int)std::min<size_t>((size_t)std::min(stack_size, kLdsStackMax), (budget - fixed) / per_entry);
 			if(c->tun.path_lds_depth > 0) d = std::max(1, std::min(d, c->tun.path_lds_depth));
 			int got = 0; // the query is made with THIS want's depth, and judged against this want
-			HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, k_path<false>, kTraceThreads, path_lds_bytes(d)));
+			HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, (k_path<false, false>), kTraceThreads, path_lds_bytes(d)));
+			int got_sun = 0; // (the variant with sun-visibility queries among its rays must fit as well: the launch geometry is one)
+			HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&got_sun, (k_path<false, true>), kTraceThreads, path_lds_bytes(d)));
+			got = std::min(got, got_sun);
 			if(got >= want) { chosen = want; depth = d; }
 		}
 		if(!chosen) return fail(c, ADYPT_E_HIP, "k_path does not fit a compute unit");
 		c->path_lds_depth = depth; c->path_lds = path_lds_bytes(depth);
 		c->path_blocks = c->num_cus * chosen;
-		if(c->tun.path_verbose) fprintf(stderr, "[adypt] k_path: %d workgroups per CU, %d path slots each, LDS stack depth %d, %zu bytes of LDS\n", chosen, kPathSlots, depth, c->path_lds);
+		if(c->tun.path_verbose) fprintf(stderr, "[adypt] k_path: %d workgroups per CU, %d path slots each, LDS stack depth %d, %zu bytes of LDS; a hit's triangle record by %s\n", chosen, kPathSlots, depth, c->path_lds,
+		                                c->d_ref_triangles ? "reference index (per-reference copy of the records)" : "uTriIndices remap in the shading round (no per-reference copy)");
 	}
 	return ensure_spill(c, stack_size);
 }
@@ -412,8 +418,14 @@ int launch_path(adypt_ctx *c, const Pipe &pipe, const QueueWindow &win, int pari
 	a.b0 = b0; a.tmin = c->params.ray_tmin;
 	hipEvent_t *stop = begin_timing(c, 2, pipe.stream);
 	const PathKernArgs K{a, f, sc, px, stats ? 1 : 0};
-	if(stats) hipLaunchKernelGGL(k_path<true>, dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, K);
-	else hipLaunchKernelGGL(k_path<false>, dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, K);
+	// (the SUN variant: rays that end at their first accepted triangle among the others — only where the queue can hold such queries)
+	if(f.sun_query)
+	{
+		if(stats) hipLaunchKernelGGL((k_path<true, true>), dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, K);
+		else hipLaunchKernelGGL((k_path<false, true>), dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, K);
+	}
+	else if(stats) hipLaunchKernelGGL((k_path<true, false>), dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, K);
+	else hipLaunchKernelGGL((k_path<false, false>), dim3(c->path_blocks), dim3(kTraceThreads), c->path_lds, pipe.stream, K);
 	end_timing(stop, pipe.stream);
 	HIP_TRY(c, hipGetLastError());
 	return ADYPT_OK;
@@ -475,6 +487,7 @@ void fill_frame(const adypt_ctx *c, FrameArgs *f)
 	f->n_local_px = c->n_local_px; f->blocks_x = c->blocks_x; f->rank = c->rank; f->nranks = c->nranks;
 	f->n_tris = (int32_t)c->n_tris; f->n_mats = (int32_t)c->n_mats; f->n_tex = c->n_tex;
 	f->deal_chunks = c->deal_chunks;
+	memcpy(f->sun_query_dir, c->sun_dir, 12); f->sun_query = 0; // (set by the frame driver where the one-launch pipeline carries the query)
 }
 void fill_scene(const adypt_ctx *c, SceneArgs *s)
 {
@@ -777,6 +790,7 @@ void roll_frame_args(const adypt_ctx *c, int frame, int s, FrameArgs *f)
 {
 	fill_frame(c, f);
 	f->spp = frame; f->n_frames = 1; f->frame_first = 0; f->frame_stride = 1; f->batched = 1;
+	f->sun_query = c->sun_visibility; // (a rolling frame always takes the one-launch pipeline: the escaped paths' queries travel with it)
 	f->sobol = c->d_sobol + (size_t)s * 64;
 	f->done = c->d_done + (size_t)s * (size_t)std::max(c->n_local_px, 64);
 }
@@ -810,7 +824,7 @@ int roll_launch(adypt_ctx *c, const SceneArgs &sc, const PixelArgs &px, bool sta
 	end_timing(stop, c->stream);
 	HIP_TRY(c, hipGetLastError());
 	c->last_batch_fused = true;
-	if(c->params.max_bounce > 1)
+	if(c->params.max_bounce > 1 || c->sun_visibility) // (with one bounce the queue still holds the sun-visibility queries of the paths that escaped at once)
 	{
 		HIP_TRY(c, hipEventRecord(c->roll_ready[s], c->stream));
 		HIP_TRY(c, hipStreamWaitEvent(pipe.stream, c->roll_ready[s], 0));
@@ -896,7 +910,14 @@ Tunables read_tunables()
 	t.path_verbose = flag("ADYPT_PATH_VERBOSE", 0);
 	t.ref_triangles_max_mb = num("ADYPT_REF_TRIANGLES_MAX_MB", 0, 1 << 20, -1);
 	if(const char *v = getenv("ADYPT_RCCL_LIB")) t.rccl_lib = v;
-	if(const char *v = getenv("ADYPT_GATHER_TIMEOUT")) { const double x = atof(v); t.gather_timeout_s = x >= 0.0 && x <= 86400.0 ? x : t.gather_timeout_s; }
+	if(const char *v = getenv("ADYPT_GATHER_TIMEOUT"))
+	{
+		// (a value that is not a number leaves the default in place: atof would read "abc" as 0 = no watchdog)
+		char *end = nullptr;
+		const double x = strtod(v, &end);
+		if(end != v && *end == '\0' && x >= 0.0 && x <= 86400.0) t.gather_timeout_s = x;
+		else fprintf(stderr, "[adypt] ADYPT_GATHER_TIMEOUT=\"%s\" is not a number of seconds in [0, 86400]: keeping %g s\n", v, t.gather_timeout_s);
+	}
 	if(test_hooks_enabled())
 	{
 		t.multi_shared_device = flag("ADYPT_MULTI_SHARED_DEVICE", 0) != 0;
@@ -1112,7 +1133,7 @@ int adypt_create(adypt_ctx **out, const adypt_scene_desc *d)
 		// uTriIndices remap (traversal.glsl:253-254) in its shading round instead — same image.
 		const size_t n16 = (size_t)c->n_refs * kTriFloat4, bytes = std::max<size_t>(n16, 1) * sizeof(float4);
 		const long max_mb = c->tun.ref_triangles_max_mb >= 0 ? c->tun.ref_triangles_max_mb : kRefTrianglesAutoMaxMB;
-		if((bytes >> 20) <= (size_t)max_mb)
+		if(max_mb != 0 && (bytes >> 20) <= (size_t)max_mb) // (0 = never, whatever the size: the tests' way into the remap path with scenes of a few triangles)
 		{
 			if(hipMalloc(&c->d_ref_triangles, bytes) != hipSuccess) { c->d_ref_triangles = nullptr; (void)hipGetLastError(); }
 			else if(n16)
@@ -1410,7 +1431,9 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		const int m = c->lookahead ? c->frames_in_flight : std::min(remaining, c->frames_in_flight);
 		const int hand_out = std::min(remaining, m);
 		// One frame per pass through the one-launch pipeline: a rolling single frame (frame k + 1 is enqueued under the end of frame k's k_path)
-		if(m == 1 && c->single_fused && c->first_fused && c->fused_bounces && !c->sun_visibility && (int64_t)c->n_local_px <= kPathMaxPaths)
+		// (the sun-visibility query rides in k_path as bounce index kPwShadow = 31: with 32 bounces configured the launch-per-bounce pipeline keeps it)
+		const bool sun_ok = !c->sun_visibility || max_bounce <= (int)kPwShadow;
+		if(m == 1 && c->single_fused && c->first_fused && c->fused_bounces && sun_ok && (int64_t)c->n_local_px <= kPathMaxPaths)
 		{
 			int r = trace_rolling_frame(c, sc, px, stats, remaining > 1);
 			if(r != ADYPT_OK) return r;
@@ -1427,13 +1450,12 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 			if(r != ADYPT_OK) return r;
 			fill_pixels(c, &px);
 		}
-		if(c->sun_visibility) { int r = ensure_shadow_queue(c); if(r != ADYPT_OK) return r; }
 		FrameArgs f;
 		fill_frame(c, &f);
 		{ int r = upload_sobol(c, c->spp, m, c->d_sobol); if(r != ADYPT_OK) return r; } // Sobol::Next (src/Util/Sobol.cpp:16-21) for the m frames of the batch
 		// A single frame (no look-ahead, or one frame in flight) runs as a batch of one — camera launch, k_shade_first, k_path, k_resolve: 4 launches
 		// instead of 1 + 2 x maxBounce — whenever a batch would take the one-launch pipeline (ADYPT_SINGLE_FUSED=0: the launch-per-bounce frame)
-		const bool as_batch = m > 1 || (c->single_fused && c->first_fused && c->fused_bounces && !c->sun_visibility && (int64_t)c->n_local_px <= kPathMaxPaths);
+		const bool as_batch = m > 1 || (c->single_fused && c->first_fused && c->fused_bounces && sun_ok && (int64_t)c->n_local_px <= kPathMaxPaths);
 		const int use_cache = (!as_batch && n_retrace) ? 0 : 1;
 		f.batched = as_batch ? 1 : 0;
 		if(as_batch && n_retrace)
@@ -1451,9 +1473,12 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		// maxBounce on pipe k's stream in window k of the queues.  Everything before this point (Sobol upload, primary-only
 		// pass, the previous batch's k_resolve) is ordered before every chain by the fork event, every chain before k_resolve.
 		const int n_pipes = m > 1 ? std::max(1, std::min(std::min(c->pipeline, kMaxPipes), m)) : 1;
-		// batches start every frame from a cached primary hit: camera rays and bounce 0 in one kernel (k_shade_first) unless the escaped paths
-		// need the sun-visibility queue
-		const bool fused_first = as_batch && use_cache && !c->sun_visibility && c->first_fused;
+		// batches start every frame from a cached primary hit: camera rays and bounce 0 in one kernel (k_shade_first).  With the sun-visibility query on, only when
+		// k_path follows (it traces the queries k_shade_first emits for the paths that escape at once); else the launch-per-bounce pipeline and its query queue
+		const bool path_ok = n_pipes == 1 && c->fused_bounces && (int64_t)m * (int64_t)c->n_local_px <= kPathMaxPaths;
+		const bool fused_first = as_batch && use_cache && c->first_fused && (!c->sun_visibility || (path_ok && sun_ok));
+		f.sun_query = (c->sun_visibility && fused_first) ? 1 : 0;
+		if(c->sun_visibility && !f.sun_query) { int r = ensure_shadow_queue(c); if(r != ADYPT_OK) return r; }
 		// the counters of all pipes are contiguous: one clearing launch, on the context's stream, before the chains fork
 		clear_counters(c, c->d_counters, n_pipes, c->stream);
 		// a launch or HIP call that fails between the fork and the join must not leave the other chains running unjoined: what follows on the
@@ -1505,7 +1530,7 @@ int adypt_trace_spp_async(adypt_ctx *c, int n_spp)
 		// every bounce after the first in ONE launch (k_path): the reference's for(b < uMaxBounce) inside a single dispatch
 		const bool fused_bounces = fused_first && n_pipes == 1 && c->fused_bounces && (int64_t)m * (int64_t)c->n_local_px <= kPathMaxPaths;
 		c->last_batch_fused = fused_bounces;
-		if(fused_bounces && max_bounce > 1)
+		if(fused_bounces && (max_bounce > 1 || f.sun_query))
 		{
 			const Pipe &pipe = c->pipes[0];
 			SceneArgs sc_ref = sc; // the triangle records by REFERENCE index when the context holds that copy, else the uTriIndices remap inside k_path

@@ -207,6 +207,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 	};
 
 	constexpr bool kOverflowPerRay = true;
+	constexpr bool kTripShadowRays = false; // (a launch of k_trace is closest-hit or any-hit as a whole: ANY)
 	const float4 *const trip_woop = a.woop; // (the trip's two base pointers: traverse_trip.inc)
 	const uint4 *const trip_nodes = a.nodes;
 	for(;;)
@@ -380,7 +381,9 @@ __device__ __forceinline__ void trace_loop(const TraceArgs a)
 		}
 		else
 #define ADYPT_TRIP_TAKE_HIT(u, v, idx) { hit_u = (u); hit_v = (v); hit_idx = (int32_t)(idx); }
+#define ADYPT_TRIP_SHADOW false
 #include "traverse_trip.inc"
+#undef ADYPT_TRIP_SHADOW
 #undef ADYPT_TRIP_TAKE_HIT
 	}
 

@@ -58,7 +58,7 @@ TRIP_EDITS = [
     ("			auto pull = [](uint32_t lane4, uint32_t v)", "			asm volatile(\"; ADYPT_MARK sec_B\");\n			auto pull = [](uint32_t lane4, uint32_t v)"),
     ("			float tt, tu, tv;\n", "			asm volatile(\"; ADYPT_MARK sec_C\");\n			float tt, tu, tv;\n"),
     ("			if(tg_y != 0)\n			{\n				// more triangles of this node", "			asm volatile(\"; ADYPT_MARK sec_D\");\n			if(tg_y != 0)\n			{\n				// more triangles of this node"),
-    ("			if(active && tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))", "			asm volatile(\"; ADYPT_MARK sec_E\");\n			if(active && tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || (ANY && hit_idx != -1)))"),
+    ("			if(active && tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || ((ANY || kTripShadowRays) && lane_any && won)))", "			asm volatile(\"; ADYPT_MARK sec_E\");\n			if(active && tg_y == 0 && !pending && ((ng_y <= 0x00ffffffu && sp == 0) || ((ANY || kTripShadowRays) && lane_any && won)))"),
     ("			if(can_pop)\n			{\n				--sp;", "			if(can_pop)\n			{\n				" + enter("A_pop") + "\n				--sp;"),
     ("					const uint2 g = my_spill[(size_t)(sp - a.lds_depth) * total_lanes];\n					ng_x = g.x; ng_y = g.y;\n					asm volatile(\"\" : \"+v\"(ng_x), \"+v\"(ng_y));\n				}\n			}",
      "					" + enter("A_pop_spill") + "\n					const uint2 g = my_spill[(size_t)(sp - a.lds_depth) * total_lanes];\n					ng_x = g.x; ng_y = g.y;\n					asm volatile(\"\" : \"+v\"(ng_x), \"+v\"(ng_y));\n					" + leave("A_pop_spill") + "\n				}\n				" + leave("A_pop") + "\n			}"),
@@ -73,9 +73,9 @@ TRIP_EDITS = [
     ("				n0 = trip_ld(np); n1 = trip_ld(np + 1); n2 = trip_ld(np + 2); n3 = trip_ld(np + 3); n4 = trip_ld(np + 4);\n			}", "				n0 = trip_ld(np); n1 = trip_ld(np + 1); n2 = trip_ld(np + 2); n3 = trip_ld(np + 3); n4 = trip_ld(np + 4);\n				" + leave("B_node_load") + "\n			}"),
     ("			if(do_test)\n			{\n				if(STATS) wave_event(2);", "			if(do_test)\n			{\n				" + enter("C_woop") + "\n				if(STATS) wave_event(2);"),
     ("				geom_ok = tt > t_tmin && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f;\n			}", "				geom_ok = tt > t_tmin && tu >= 0.0f && tu <= 1.0f && tv >= 0.0f && tu + tv <= 1.0f;\n				" + leave("C_woop") + "\n			}"),
-    ("				pending = false;\n				if(ANY) overflow |= push_overflow;", "				" + enter("D_slab") + "\n				pending = false;\n				if(ANY) overflow |= push_overflow;"),
+    ("				pending = false;\n				if(ANY || kTripShadowRays) overflow |= push_overflow;", "				" + enter("D_slab") + "\n				pending = false;\n				if(ANY || kTripShadowRays) overflow |= push_overflow;"),
     ("				tg_y = hitmask & 0x00ffffffu;\n			}", "				tg_y = hitmask & 0x00ffffffu;\n				" + leave("D_slab") + "\n			}"),
-    ("				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert", "				" + enter("E_flush") + "\n				if(ANY) { ng_y = 0; sp = 0; } // an any-hit ray ends with work left: make the lane inert"),
+    ("				if(ANY || kTripShadowRays) { if(lane_any) { ng_y = 0; sp = 0; } } // an any-hit ray ends with work left: make the lane inert", "				" + enter("E_flush") + "\n				if(ANY || kTripShadowRays) { if(lane_any) { ng_y = 0; sp = 0; } } // an any-hit ray ends with work left: make the lane inert"),
     ("				active = false;\n			}\n		}", "				active = false;\n				" + leave("E_flush") + "\n			}\n		}"),
 ]
 if LANES and SET == "wait":
@@ -94,8 +94,8 @@ zero = " ".join('asm volatile("s_mov_b32 s%d, 0" ::: "s%d");' % (r, r) for r in 
 read = " ".join('asm volatile("s_mov_b32 %%0, s%d" : "=s"(bc[%d]));' % (96 + i, i) for i in range(6))
 SHADE_PATH = [
     ("						if(parked) r4 = f.done[pi];", "						if(parked) { " + enter("S_parked") + " r4 = f.done[pi]; " + leave("S_parked") + " }"),
-    ("							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135\n							alive = false;",
-     "							" + enter("S_miss") + "\n							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135\n							alive = false;\n							" + leave("S_miss")),
+    ("							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135 (a query that came back empty: the sun is visible)\n							alive = false;",
+     "							" + enter("S_miss") + "\n							ret = fma3(color, f3(f.sun[0], f.sun[1], f.sun[2]), ret); // pathtracer.glsl:130-135 (a query that came back empty: the sun is visible)\n							alive = false;\n							" + leave("S_miss")),
     ("							const SurfaceInfo si = fetch_info(f, sc, tc, tri_idx, tu, tv);", "							" + enter("S_surface") + "\n							const SurfaceInfo si = fetch_info(f, sc, tc, tri_idx, tu, tv);"),
     ("						if(rm != 0ull && (uint32_t)__popcll(rm) <= a.defer_max)\n						{", "						if(rm != 0ull && (uint32_t)__popcll(rm) <= a.defer_max)\n						{\n							" + enter("S_defer")),
     ("							have = have && !defer;\n						}", "							have = have && !defer;\n							" + leave("S_defer") + "\n						}"),
@@ -140,8 +140,8 @@ pairs = SHADE_PATH + [
 ]
 if COUNT:
     pairs += [
-        ("template <bool STATS>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathKernArgs K)\n{",
-         "template <bool STATS>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) __attribute__((amdgpu_num_sgpr(96))) void k_path(PathKernArgs K)\n{\n	" + zero),
+        ("template <bool STATS, bool SUN>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathKernArgs K)\n{",
+         "template <bool STATS, bool SUN>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) __attribute__((amdgpu_num_sgpr(96))) void k_path(PathKernArgs K)\n{\n	" + zero),
         ("	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------",
          "	{ uint32_t bc[6]; " + read + "\n	if(lane == 0) for(int i = 0; i < 6; ++i) atomicAdd(&a.stats->wave_profile[i], " + ("(unsigned long long)bc[i]" if LANES else "(((unsigned long long)(bc[i] >> 16)) << 32) | (unsigned long long)(bc[i] & 0xffffu)") + "); } // (k_path<false> leaves wave_profile alone)\n"
          "	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------"),

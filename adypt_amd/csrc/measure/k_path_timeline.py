@@ -9,7 +9,7 @@ At the end of the launch lane 0 of every wave adds its sums to DeviceStats::wave
     [4] triangle fetch  : what is left of the triangle loads' latency when the Woop arithmetic wants them (s_waitcnt vmcnt(5))
     [5] C               : Woop test, verdicts back, winner's (u, v, index) back (two LDS round trips), hit stored
     [6] D + E           : the rest of the node loads' latency, the slab test, the finished-ray check
-    [7] trips << 40 | cost of one stamp, summed (a back-to-back stamp at the end of every trip: every section above contains one such cost)
+    [7] trips << 36 | cost of one stamp, summed (a back-to-back stamp at the end of every trip: every section above contains one such cost)
     tools/build_variant.sh timeline --transform adypt_amd/csrc/measure/k_path_timeline.py [--transform adypt_amd/csrc/measure/k_path_init_cap.py]"""
 import sys
 d = sys.argv[1]
@@ -44,11 +44,11 @@ edit("traverse_trip.inc", [
 zero = " ".join('asm volatile("s_mov_b32 s%d, 0" ::: "s%d");' % (r, r) for r in range(88, 98)) + ' asm volatile("s_memtime s[100:101]\\n\\ts_waitcnt lgkmcnt(0)\\n\\ts_mov_b32 s98, s100" ::: "s98", "s100", "s101");'
 read = " ".join('asm volatile("s_mov_b32 %%0, s%d" : "=s"(tl[%d]));' % (88 + i, i) for i in range(9))
 edit("path.hpp", [
-    ("template <bool STATS>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathKernArgs K)\n{",
-     "template <bool STATS>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) __attribute__((amdgpu_num_sgpr(88))) void k_path(PathKernArgs K)\n{\n	" + zero),
+    ("template <bool STATS, bool SUN>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k_path(PathKernArgs K)\n{",
+     "template <bool STATS, bool SUN>\n__global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) __attribute__((amdgpu_num_sgpr(88))) void k_path(PathKernArgs K)\n{\n	" + zero),
     ("	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------",
      "	{ uint32_t tl[9]; " + read + "\n	if(lane == 0) { for(int i = 0; i < 7; ++i) atomicAdd(&a.stats->wave_profile[i], (unsigned long long)tl[i]);\n"
-     "		atomicAdd(&a.stats->wave_profile[7], ((unsigned long long)tl[7] << 40) | (unsigned long long)tl[8]); } } // (k_path<false> leaves wave_profile alone)\n"
+     "		atomicAdd(&a.stats->wave_profile[7], ((unsigned long long)tl[7] << 36) | (unsigned long long)tl[8]); } } // (k_path<false> leaves wave_profile alone)\n"
      "	// ---------------- totals: per wave -> per workgroup (LDS) -> one device atomic per workgroup ----------------"),
 ])
 # (k_trace includes the trip too: its stamps write the same fixed registers, which that kernel never reads — it is not held to 88 SGPRs, so it must not be run

@@ -38,6 +38,17 @@ def _launcher_start_time() -> float:
         return 0.0
 
 
+def _proc_start_ticks(pid: int) -> int:
+    """starttime of process `pid` (field 22 of /proc/pid/stat, clock ticks since boot); -1 when there is no such process, -2 when /proc does not say."""
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            return int(f.read().rsplit(")", 1)[1].split()[19])
+    except FileNotFoundError:
+        return -1
+    except (OSError, ValueError, IndexError):
+        return -2
+
+
 def block_count(width: int, height: int, rank: int, world: int) -> int:
     n = N.lib.adypt_shard_block_count(width, height, rank, world)
     if n < 0:
@@ -185,7 +196,9 @@ def exchange_unique_id(rank: int, world: int, path: Optional[str] = None, make_i
             os.unlink(tmp)
         except OSError:
             pass
-        _write_new(tmp, uid)
+        # the id, and who wrote it: "this file belongs to a job that is running" is then a fact a waiting rank can check (the writer — rank 0, blocked in
+        # its communicator's creation until the others arrive — is alive, and is the same incarnation of that pid), not an inference from time stamps
+        _write_new(tmp, uid + b"|writer=%d:%d\n" % (os.getpid(), _proc_start_ticks(os.getpid())))
         os.replace(tmp, path)
         return uid
     t0 = time.time()
@@ -198,8 +211,22 @@ def exchange_unique_id(rank: int, world: int, path: Optional[str] = None, make_i
                     raise RuntimeError("rendezvous file %s belongs to another user" % path)
                 uid = f.read()
             # an id left behind by an EARLIER job that died before rank 0 could remove it (same launcher port, back-to-back runs) must not be taken
-            # for this job's: only a file written after this job's LAUNCHER started counts
-            if st.st_mtime < _launcher_start_time() - 2.0:
+            # for this job's.  A file this module wrote names its writer: stale = that process is gone (or its pid belongs to a later process).  Only a
+            # bare 128-byte file (written by something else) falls back to the time stamp: it counts if it is younger than this rank's PARENT — which is
+            # the job's launcher when one parent starts every rank (torch.distributed.run, tools/comm_world.py), the case that heuristic was made for.
+            tag = uid[128:]
+            uid = uid[:128]
+            if tag.startswith(b"|writer=") and tag.endswith(b"\n"):
+                try:
+                    wpid, wticks = (int(x) for x in tag[8:-1].split(b":"))
+                    now = _proc_start_ticks(wpid)
+                    if now == -1 or (now >= 0 and wticks >= 0 and now != wticks):
+                        uid = b""
+                except ValueError:
+                    uid = b""
+            elif tag:
+                uid = b"" if uid + tag != b"failed" else b"failed"
+            elif st.st_mtime < _launcher_start_time() - 2.0:
                 uid = b""
             if len(uid) == 128:
                 return uid

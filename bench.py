@@ -30,6 +30,7 @@ What the JSON line carries besides the contract's fields:
                          measured roof of its access pattern (gather_roof_GBs: random dependent 80-byte gathers, tools/microbench/gather_roof.hip).
   primary_only           BASELINE config 2: primary rays only (adypt_trace_primary), >= 100 calls.
   tmp_lifetime_1         the K steps with every frame tracing its primary rays (report tmpLifetime 16 and 1).
+  sun_visibility         the K steps with the optional occlusion query on: one more ray per escaped path, inside the same launch.
   single_frame           one adypt_trace_spp(ctx, 1) per call (what Instance::Update does), with the library's look-ahead; one_frame_per_pass: single frames
                          in a row (frames_in_flight 1) in one call, in synchronous calls, and in calls with one frame started ahead.
   cpu_baseline           oracle/liboracle.so on the host cores, bounded sample.
@@ -52,7 +53,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec)
 N_SIMD = 1024           # 256 CUs x 4 SIMDs
 NOMINAL_CLOCK_GHZ = 2.4 # only used when no profile supplies the clock the chip really ran the kernel at
-PMC_BENCH, PMC_SANMIGUEL, ISSUE_MODEL, GATHER_ROOF = "r5_pmc_bench.json", "r5_pmc_sanmiguel.json", "r5_valu_issue_model.json", "r5_gather_roof.json"
+PMC_BENCH, PMC_SANMIGUEL, PMC_PRIMARY, ISSUE_MODEL, GATHER_ROOF = "r6_pmc_bench.json", "r6_pmc_sanmiguel.json", "r6_pmc_primary.json", "r6_valu_issue_model.json", "r5_gather_roof.json"
 PT_CFG = {"maxBounce": 8, "subpixel": 8, "clamp": 4.0, "sun": [12.0, 11.0, 10.0], "stackSize": 24}
 SEED = 12345
 
@@ -129,7 +130,7 @@ def traffic_fields(pmc, rays, launches, kernel_rays_s):
 def dominant(st):
     """Which kernel the roofline is about: k_path when the batches ran their bounces in one launch, else the traversal kernel."""
     if st.get("path_launches", 0) > 0:
-        return {"kernel": "k_path<false>", "ms": st["path_ms"], "launches": st["path_launches"], "rays": st["path_rays"], "fused": True}
+        return {"kernel": "k_path<false, false>", "ms": st["path_ms"], "launches": st["path_launches"], "rays": st["path_rays"], "fused": True}
     return {"kernel": "k_trace<false, false>", "ms": st["trace_ms"], "launches": st["trace_launches"], "rays": st["rays"], "fused": False}
 
 
@@ -189,7 +190,7 @@ def roofline_block(dom, cs, pmc_name, live_clock, bvh_mb, note_extra="", binds="
         pmc, why = None, "profiles/%s holds %s, this run's dominant kernel is %s" % (pmc_name, pmc.get("kernel"), dom["kernel"])
     if pmc:
         out.update(traffic_fields(pmc, rays, launches, rays_s))
-        out.update({"achieved": out["traffic_GBs"], "frac": out["traffic_frac_of_hbm_peak"], "pmc_stale": False, "bound": binds,
+        out.update({"achieved": out["traffic_GBs"], "frac": out["traffic_frac_of_hbm_peak"], "frac_fabric_traffic_of_hbm_peak": out["traffic_frac_of_hbm_peak"], "pmc_stale": False, "bound": binds,
                     "frac_of": "fabric traffic (PMC FETCH_SIZE x 2 + WRITE_SIZE per ray, committed profile replayed against this run's live rays/s) / 8 TB/s HBM peak; "
                                "`bound` names what binds the kernel, which on this scene is NOT this resource: see valu_issue",
                     "traffic_over_algorithmic": round(pmc["traffic_bytes_per_ray"] / (cs["k_alg_bytes"] / max(1, cs["k_rays"])), 3),
@@ -293,8 +294,9 @@ def main() -> None:
     ap.add_argument("--no-single-frame", action="store_true")
     ap.add_argument("--no-extra-blocks", action="store_true", help="skip primary_only and tmp_lifetime_1")
     ap.add_argument("--cache", default=os.environ.get("ADYPT_CACHE", os.path.join(ROOT, ".adypt_cache")))
-    ap.add_argument("--selfcheck", action="store_true", help="N > 1 (the default there): before anything is timed, render 2 frames on the N GPUs and on GPU 0 alone and compare the two images bit for bit; exit 3 on a mismatch")
-    ap.add_argument("--no-selfcheck", action="store_true", help="N > 1: skip that check")
+    ap.add_argument("--selfcheck", action="store_true", help="(accepted for older command lines; the check below is the default for N > 1 and this flag changes nothing)")
+    ap.add_argument("--no-selfcheck", action="store_true", help="N > 1: skip the self-check — before anything is timed, 2 frames are rendered on the N GPUs and on GPU 0 alone and the two images "
+                    "compared bit for bit (exit 3 on a mismatch); it is also skipped, and says so in config.selfcheck, when GPU 0 has no room for a second context of the scene")
     ap.add_argument("--rehearsal", action="store_true", help="NOT a measurement: enables the library's test hooks (adypt_enable_test_hooks) so that ADYPT_MULTI_SHARED_DEVICE / "
                                                              "ADYPT_COMM_TRANSPORT=host can stand in for N GPUs on a box with one")
     args = ap.parse_args()
@@ -439,8 +441,19 @@ def main() -> None:
             img_n = pt.CommReadResult()
         bad = 0.0
         if rank == 0:
-            solo = api.HipPathTracer()  # the whole image on this rank's device alone
+            # the whole image on this rank's device alone: a SECOND context beside the N-GPU one — the scene again (with its per-reference copy of the
+            # triangle records: 1.3 GB for the 10 M-triangle stand-in) and queues for two frames.  Not attempted without room for it.
+            h = inst.m_hipscene
+            # (nodes 80 B, references 52 B + their copy of the 128-byte triangle records, triangles 128 B; queues ~200 B per path of two frames; 1 GB of slack)
+            need = len(h.bvh.nodes) * 80 + len(h.bvh.tri_indices) * (52 + 128) + len(h.scene.triangles) * 128 + c.width * c.height * 2 * 200 + (1 << 30)
+            free = api.device_free_bytes(0 if multi else dev)
+        if rank == 0 and free is not None and free < need:
+            selfcheck = {"skipped": "device memory: %.1f GB free, a second context of this scene wants ~%.1f GB" % (free / 1e9, need / 1e9)}
+            sys.stderr.write("bench.py: self-check skipped (%s)\n" % selfcheck["skipped"])
+        elif rank == 0:
+            solo = api.HipPathTracer()
             solo.Initialize(inst.m_config.pt_params(SEED), inst.m_hipscene, c.width, c.height, 0 if multi else dev, 0, 1)
+            solo.SetFramesInFlight(2)
             ip, iv = inst.m_camera.matrices()
             solo.SetCamera(ip, iv, inst.m_camera.position)
             solo.Trace(True, 2)
@@ -515,7 +528,7 @@ def main() -> None:
 
     single_gpu = world == 1 and not multi
     extras = single_gpu and rank == 0
-    roofline = primary_only = life1 = single = hbm = cpu = None
+    roofline = primary_only = life1 = single = hbm = cpu = sun_vis = None
     if extras:
         # ---- census (untimed): the same K frames again through the instrumented kernels -> exact algorithmic bytes ------
         dom = dict(dominant(st), rays_warmup=dominant(warm_stats)["rays"])
@@ -540,7 +553,31 @@ def main() -> None:
             s2 = pt.GetStats()
             primary_only = {"workload": "BASELINE config 2: %dx%d, primary rays only, viewer type 0, %d calls of adypt_trace_primary (one traversal launch each)" % (c.width, c.height, n_calls),
                             "rays_per_call": int(s2["rays"] // n_calls), "Mrays_s_per_call": round(s2["rays"] / dt / 1e6, 1), "ms_per_call": round(dt * 1e3 / n_calls, 4),
-                            "kernel_Mrays_s": round(s2["rays"] / s2["trace_ms"] / 1e3, 1), "kernel_ms_per_call": round(s2["trace_ms"] / n_calls, 4)}
+                            "kernel_Mrays_s": round(s2["rays"] / s2["trace_ms"] / 1e3, 1), "kernel_ms_per_call": round(s2["trace_ms"] / n_calls, 4),
+                            "kernel": "k_trace_camera<false, true>", "kernel_rays": int(s2["rays"]), "kernel_rays_warmup": int(s2["rays"] // n_calls) * 8}
+            # its roofline: SURVEY.md 8(d) bytes from one instrumented call (exact node / triangle census of the same rays), counter figures from the committed
+            # rocprofv3 --pmc passes of this very command (tools/collect_profiles.sh primary: every launch of this kernel name belongs to this block)
+            pt.SetInstrumentation(timing=False, counters=True)
+            pt.ResetStats()
+            pt.Trace(False)
+            s2c = pt.GetStats()
+            pt.SetInstrumentation(timing=True, counters=False)
+            k_rays_s = s2["rays"] / (s2["trace_ms"] * 1e-3)
+            alg = (80.0 * s2c["nodes_visited"] + 48.0 * s2c["tris_tested"] + 4.0 * s2c["hits"]) / max(1, s2c["rays"]) + 32.0  # + the hit and the colour written per pixel (2 x float4)
+            primary_only.update({"nodes_per_ray": round(s2c["nodes_visited"] / max(1, s2c["rays"]), 2), "tris_per_ray": round(s2c["tris_tested"] / max(1, s2c["rays"]), 2),
+                                 "hits_per_ray": round(s2c["hits"] / max(1, s2c["rays"]), 3), "alg_bytes_per_ray": round(alg, 1),
+                                 "alg_GBs": round(alg * k_rays_s / 1e9, 1), "alg_frac_of_hbm_peak": round(alg * k_rays_s / 1e9 / HBM_PEAK_GBS, 4)})
+            pmc2, why2 = counter_figures(PMC_PRIMARY)
+            if pmc2 and pmc2.get("kernel") == primary_only["kernel"]:
+                clock = live_clock if live_clock and live_clock > 0.5 else NOMINAL_CLOCK_GHZ
+                primary_only.update(traffic_fields(pmc2, s2["rays"], n_calls, k_rays_s))
+                primary_only.update({"valu_insts_per_ray": round(pmc2["valu_insts_per_ray"], 2), "lane_util": round(pmc2["lane_util"], 4), "vmem_rd_insts_per_ray": round(pmc2.get("vmem_rd_insts_per_ray", 0.0), 3),
+                                     "valu_issue_cycles_available_per_inst": round(N_SIMD * clock * 1e9 / (pmc2["valu_insts_per_ray"] * k_rays_s), 3),
+                                     "traffic_over_algorithmic": round(pmc2["traffic_bytes_per_ray"] / alg, 3), "pmc_stale": False,
+                                     "bound": "the end of the launch (5.3 rays per lane: the launch is ramping down from its first reservation on) on top of vector-ALU issue",
+                                     "note": "coherent rays: fewer distinct lines per fetch than k_path's, the same trip; in-kernel rate against k_path's = what the ramp-down of a 2 M-ray launch costs"})
+            else:
+                primary_only.update({"pmc_stale": True, "note": "no counter figures: " + (why2 or "profiles/%s holds another kernel" % PMC_PRIMARY)})
             # ---- the same K steps with tmpLifetime 1: every frame traces its primary rays ----
             params = inst.m_config.pt_params(SEED)
             params.tmp_lifetime = 1
@@ -559,6 +596,23 @@ def main() -> None:
                      "Mrays_s": round(s3["rays"] / dt / 1e6, 1), "ms_per_step": round(dt * 1e3 / args.steps, 4), "rays_per_step": int(s3["rays"] // args.steps),
                      "trace_kernels_ms": round(s3["trace_ms"], 2), "other_kernels_ms": round(s3["shade_ms"], 2)}
             pt.SetConfig(inst.m_config.pt_params(SEED))
+            pt.Reset()
+            # ---- the same K steps with the sun-visibility query on (pathtracer.glsl:132, commented out in the reference): every escaped path
+            # sends one more ray towards the sun, inside the same k_path launch (k_path<., SUN>); the queries are rays of the census ----
+            pt.SetSunVisibility(True)
+            if args.warmup:
+                pt.Trace(True, args.warmup)
+            pt.ResetStats()
+            pt.DeviceSynchronize()
+            t1 = time.perf_counter()
+            pt.Trace(True, args.steps)
+            pt.DeviceSynchronize()
+            dt = time.perf_counter() - t1
+            s4 = pt.GetStats()
+            sun_vis = {"workload": "the timed region's %d steps after %d warm-up with adypt_set_sun_visibility on: one any-hit query per escaped path, traced inside the same launch" % (args.steps, args.warmup),
+                       "Mrays_s": round(s4["rays"] / dt / 1e6, 1), "ms_per_step": round(dt * 1e3 / args.steps, 4), "rays_per_step": int(s4["rays"] // args.steps),
+                       "one_launch_pipeline": bool(pt.GetFusedBounces()), "rate_vs_option_off": round((s4["rays"] / dt) / (total_rays / elapsed), 4)}
+            pt.SetSunVisibility(False)
             pt.Reset()
 
         # ---- one frame per call (Instance::Update -> Trace(true), src/Instance.cpp:44-57) with the library's look-ahead ----------
@@ -646,7 +700,7 @@ def main() -> None:
                           "setup_s": round(t_setup, 2),
                           "setup_s_per_device": [round(pt.SetupSeconds(i), 3) for i in range(n_gpus)] if multi else None,
                           "selfcheck": selfcheck, "rehearsal": bool(args.rehearsal)},
-               "roofline": roofline, "roofline_hbm_resident": hbm, "cpu_baseline": cpu, "primary_only": primary_only, "tmp_lifetime_1": life1, "single_frame": single,
+               "roofline": roofline, "roofline_hbm_resident": hbm, "cpu_baseline": cpu, "primary_only": primary_only, "tmp_lifetime_1": life1, "sun_visibility": sun_vis, "single_frame": single,
                "gather_ms": round(gather_ms, 3), "other_kernels_ms": round(st["shade_ms"], 2), "trace_kernels_ms": round(st["trace_ms"], 2),
                "per_rank": None if per_rank is None else {
                    "wall_ms": [round(float(v), 3) for v in per_rank[:, 0]], "trace_kernels_ms": [round(float(v), 3) for v in per_rank[:, 1]],

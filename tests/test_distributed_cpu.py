@@ -171,3 +171,18 @@ def test_a_stale_id_of_an_earlier_job_is_not_taken_for_this_jobs(tmp_path):
         D.exchange_unique_id(1, 2, path=path, timeout_s=0.5)         # the stale id is not returned
     assert D.exchange_unique_id(0, 2, path=path, make_id=lambda: bytes(range(128))) == bytes(range(128))
     assert D.exchange_unique_id(1, 2, path=path, timeout_s=5.0) == bytes(range(128))
+    # a file this module wrote names its writer: an id whose writer is gone is stale however young the file is (a rank started by a wrapper of its
+    # own, whose parent is younger than rank 0's file, must not reject a LIVE writer's id either: no time stamp is consulted for such files)
+    with open(path, "wb") as f:
+        f.write(b"\xee" * 128 + b"|writer=%d:%d\n" % (2 ** 22 - 3, 12345))       # no such process
+    with pytest.raises(TimeoutError):
+        D.exchange_unique_id(1, 2, path=path, timeout_s=0.5)
+    with open(path, "wb") as f:
+        f.write(b"\xee" * 128 + b"|writer=%d:%d\n" % (os.getpid(), D._proc_start_ticks(os.getpid()) + 1))   # this pid, an earlier incarnation
+    with pytest.raises(TimeoutError):
+        D.exchange_unique_id(1, 2, path=path, timeout_s=0.5)
+    with open(path, "wb") as f:
+        f.write(b"\xaa" * 128 + b"|writer=%d:%d\n" % (os.getpid(), D._proc_start_ticks(os.getpid())))
+    old = time.time() - 30 * 86400
+    os.utime(path, (old, old))                                                   # ... old time stamp, live writer: taken
+    assert D.exchange_unique_id(1, 2, path=path, timeout_s=5.0) == b"\xaa" * 128

@@ -196,21 +196,30 @@ def test_sun_visibility_option_matches_oracle(name, w, h, fif, scene_cache, sobo
     common = dict(stack_size=c.stack_size, max_bounce=c.max_bounce, subpixel=c.subpixel, tmp_life=c.tmp_lifetime, tmin=c.ray_tmin,
                   clamp=c.clamp, sun=list(c.sun))
     pt.SetFramesInFlight(fif)
-    pt.SetInstrumentation(counters=True)
     results = {}
     for label, direction in (("off", None), ("default", None), ("custom", [-0.3, 0.8, 0.5])):
         on = label != "off"
-        pt.SetSunVisibility(on, direction)
-        pt.Reset()
-        pt.ResetStats()
-        pt.Trace(True, 7)
-        img, g = pt.ReadResult(), pt.GetStats()
         P = O.make_params(c.width, c.height, list(c.position), ip, iv, sun_visibility=on,
                           sun_dir=direction if direction is not None else (0.6, 1.0, 0.2), **common)
         st = O.PathTracerState(c.width, c.height)
         ost = O.pt_frames(osc, P, O.shift_bytes(21, c.width, c.height), sobol_matrices, st, 7).as_dict()
-        assert np.array_equal(bits(img), bits(st.accum[..., :3])), label
-        assert (g["rays"], g["nodes_visited"], g["tris_tested"], g["hits"], g["shaded"]) == (ost["rays"], ost["nodes"], ost["tris"], ost["hits"], ost["shaded"]), label
+        # the queries ride inside the one-launch pipeline (k_path<., SUN>: rays that end at their first accepted triangle among the others) — with the
+        # instrumented kernel (exact census: the queries visit what the oracle's any-hit queries visit) and with the product kernel — and, for comparison,
+        # through the launch-per-bounce pipeline's query queue
+        for counters, fused in ((True, True), (False, True), (True, False)):
+            pt.SetInstrumentation(counters=counters)
+            pt.SetFusedBounces(fused)
+            pt.SetSunVisibility(on, direction)
+            pt.Reset()
+            pt.ResetStats()
+            pt.Trace(True, 7)
+            assert pt.GetFusedBounces() == fused
+            img, g = pt.ReadResult(), pt.GetStats()
+            assert np.array_equal(bits(img), bits(st.accum[..., :3])), (label, counters, fused)
+            assert g["rays"] == ost["rays"], (label, counters, fused)
+            if counters:
+                assert (g["nodes_visited"], g["tris_tested"], g["hits"], g["shaded"]) == (ost["nodes"], ost["tris"], ost["hits"], ost["shaded"]), (label, fused)
+        pt.SetFusedBounces(True)
         results[label] = (img, g["rays"])
     assert results["default"][1] >= results["off"][1]                       # the queries are rays
     assert (results["default"][0] <= results["off"][0]).all()               # occlusion only removes light
@@ -388,6 +397,8 @@ def write_zoo(tmp_path):
     {"ADYPT_RARE_MIN": "0"},                                                         # no shading round defers anything
     {"ADYPT_PATH_BLOCKS_PER_CU": "1", "ADYPT_RARE_MIN": "64"},                       # long queues per workgroup: rounds defer, the deferred ring fills up and overflows
     {"ADYPT_PATH_BLOCKS_PER_CU": "1", "ADYPT_RARE_MIN": "3", "ADYPT_SHADE_MIN": "9"},
+    {"ADYPT_REF_TRIANGLES_MAX_MB": "0"},                                             # the uTriIndices remap inside the shading round (no per-reference copy of the records)
+    {"ADYPT_REF_TRIANGLES_MAX_MB": "0", "ADYPT_PATH_BLOCKS_PER_CU": "1", "ADYPT_RARE_MIN": "1"},
 ])
 def test_material_zoo_matches_oracle(env, tmp_path, sobol_matrices, monkeypatch):
     """Every branch of Render's illum switch (pathtracer.glsl:144-201) on the device: diffuse, glossy above and AT the e = Ns * 0.01 > 0.3

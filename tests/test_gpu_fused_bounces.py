@@ -105,6 +105,8 @@ def test_max_bounce_one_needs_no_launch_at_all(scene_cache):
     {"ADYPT_RARE_MIN": 7, "ADYPT_SHADE_MIN": 1, "ADYPT_REFILL_MIN": 1},
     {"ADYPT_PATH_BLOCKS_PER_CU": 1, "ADYPT_DEFER_MAX": 64, "ADYPT_RARE_MIN": 16},   # a round defers however many it finds
     {"ADYPT_PATH_BLOCKS_PER_CU": 1, "ADYPT_DEFER_MAX": 1},                          # ... only a lone one
+    {"ADYPT_REF_TRIANGLES_MAX_MB": 0},                              # no per-reference copy of the triangle records: the shading round applies uTriIndices (PathArgs::tri_remap)
+    {"ADYPT_REF_TRIANGLES_MAX_MB": 0, "ADYPT_PATH_BLOCKS_PER_CU": 1, "ADYPT_RARE_MIN": 1},   # ... and a deferred hit is remapped again when its round comes
 ])
 def test_scheduling_tunables_do_not_change_a_bit(env, scene_cache):
     pt = {"tmpLifetime": 4, "maxBounce": 7, "subpixel": 2, "stackSize": 24}
@@ -156,7 +158,11 @@ def test_which_batches_take_the_fused_launch(scene_cache):
     assert p.GetFusedBounces()                      # a single frame runs as a batch of one through the same four launches
     p.SetSunVisibility(True)
     p.Trace(True, 6)
-    assert not p.GetFusedBounces()                  # escaped paths need the sun-visibility queue
+    assert p.GetFusedBounces()                      # the escaped paths' sun-visibility queries ride in the same launch (k_path<., SUN>)
+    p.SetPipeline(2)
+    p.Trace(True, 6)
+    assert not p.GetFusedBounces()                  # ... the sub-batch pipeline sends them through the query queue
+    p.SetPipeline(1)
     p.SetSunVisibility(False)
     p.SetPipeline(2)
     p.Trace(True, 6)

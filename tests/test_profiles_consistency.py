@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 
 def test_issue_model_is_what_its_generator_prints():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_issue_model.py")], stdout=subprocess.PIPE, check=True).stdout
-    assert json.loads(out) == json.load(open(os.path.join(ROOT, "profiles", "r5_valu_issue_model.json")))
+    assert json.loads(out) == json.load(open(os.path.join(ROOT, "profiles", "r6_valu_issue_model.json")))
     m = json.loads(out)
     shares = sum(c["share"] for c in m["classes"])
     assert abs(shares - 1.0) < 0.01
@@ -24,9 +24,9 @@ def test_issue_model_is_what_its_generator_prints():
 
 
 def test_trip_budget_is_of_this_tree():
-    """profiles/r5_trip_budget.json = tools/trip_budget.py on the device sources as they are (two gfx950 compiles, no GPU)."""
+    """profiles/r6_trip_budget.json = tools/trip_budget.py on the device sources as they are (two gfx950 compiles, no GPU)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trip_budget.py")], stdout=subprocess.PIPE, check=True).stdout
-    have = json.load(open(os.path.join(ROOT, "profiles", "r5_trip_budget.json")))
+    have = json.load(open(os.path.join(ROOT, "profiles", "r6_trip_budget.json")))
     assert json.loads(out) == have
     assert abs(have["trip_valu_static_marked_build"] - have["trip_valu_static_product_build"]) <= 12  # (the marks are scheduling barriers)
 
@@ -39,7 +39,7 @@ def test_counter_profiles_have_what_bench_reads():
         for key in ("source_hash", "valu_insts_per_ray", "lane_util", "traffic_bytes_per_ray", "traffic_bytes_per_ray_uncorrected", "TCC_hit_rate",
                     "vmem_rd_insts_per_ray", "rays", "launches", "command"):
             assert key in p, (name, key)
-        assert p["kernel"] == "k_path<false>"
+        assert p["kernel"].startswith("k_path<false")
         assert 0.3 < p["lane_util"] <= 1.0 and 20 < p["valu_insts_per_ray"] < 400
         pmc, why = bench.counter_figures(name)
         # either the profile belongs to this tree, or bench.py says why not (and then reports pmc_stale instead of using it)

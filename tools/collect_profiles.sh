@@ -10,6 +10,21 @@ export TMPDIR=/tmp ADYPT_CACHE=${ADYPT_CACHE:-/tmp/adypt_cache}
 WHAT=${1:-bench}
 if [ "$WHAT" = "sanmiguel" ]; then
   TAG=sanmiguel; FULL="python3 bench.py --scene sanmiguel --steps 32 --warmup 16 --repeats 1 --no-cpu-baseline --no-single-frame --no-extra-blocks"
+elif [ "$WHAT" = "primary" ]; then
+  # BASELINE config 2: the counters of k_trace_camera<false, true> — a kernel name only bench.py's primary_only block launches (8 warm-up + 128 timed calls);
+  # four counter groups, the extra blocks left ON (tools/pmc_profile.py reads that block: PMC_BLOCK=primary_only)
+  TAG=primary; OUT=gpurun_out/profiles_$TAG; rm -rf $OUT; mkdir -p $OUT
+  CMD="python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-hbm-block --no-single-frame --repeats 1"
+  $CMD > $OUT/plain_run.json 2> /dev/null
+  for grp in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
+    tag=$(echo $grp | cut -d' ' -f1)
+    timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$tag -- $CMD > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err
+  done
+  python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
+  PMC_BLOCK=primary_only python3 tools/pmc_profile.py $OUT $OUT/pmc_FETCH_SIZE.json "rocprofv3 --pmc <group> -- $CMD" > $OUT/pmc_profile.json
+  find $OUT -name "*counter_collection.csv" -delete
+  grep -A14 "^k_trace_camera<false, true" $OUT/pmc_summary.txt; cat $OUT/pmc_profile.json
+  exit 0
 else
   TAG=bench; FULL="python3 bench.py --gpus 1 --steps 20 --warmup 5"
 fi

@@ -18,7 +18,7 @@ flags = [f for f in flags if f not in ("-fPIC",)]
 with tempfile.NamedTemporaryFile(suffix=".s") as t:
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DADYPT_BUILD", "--cuda-device-only", "-S", os.path.join(CSRC, "device/tracer.hip"), "-o", t.name], stderr=subprocess.DEVNULL)
     text = open(t.name).read()
-name = {"k_trace": "_ZN5adypt7k_traceILb0ELb0EEEvNS_9TraceArgsE", "k_path": "_ZN5adypt6k_pathILb0EEEvNS_12PathKernArgsE"}[which]
+name = {"k_trace": "_ZN5adypt7k_traceILb0ELb0EEEvNS_9TraceArgsE", "k_path": "_ZN5adypt6k_pathILb0ELb0EEEvNS_12PathKernArgsE"}[which]
 body = text[text.index("\n" + name + ":"):text.index(".amdhsa_kernel " + name)].splitlines()
 
 FULL = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_add_u32", "v_sub_u32",
@@ -93,7 +93,7 @@ tot = sum(counts.values())
 mix = {"normal_rate_4_cycles": round(counts["normal"] / tot, 3), "full_rate_2_cycles": round(counts["full"] / tot, 3),
        "packed_or_64bit_4_cycles": round(counts["packed64"] / tot, 3), "transcendental_8_cycles": round(counts["trans"] / tot, 3)}
 old = json.load(open(os.path.join(ROOT, "profiles", "r2_k_trace_instruction_mix.json")))
-print(json.dumps({"kernel": {"k_trace": "k_trace<false, false>", "k_path": "k_path<false>"}[which], "what": __doc__.split("\n    python")[0], "flags": " ".join(flags),
+print(json.dumps({"kernel": {"k_trace": "k_trace<false, false>", "k_path": "k_path<false, false>"}[which], "what": __doc__.split("\n    python")[0], "flags": " ".join(flags),
                   "valu_instructions_every_trip": n_loop, "valu_instructions_in_weighted_blocks": per_region, "block_weights": {r[0]: round(r[3], 4) for r in regions}, "weights_from": weights_from,
                   "weighted_valu_instructions_per_trip": round(tot, 1),
                   "mix": mix, "avg_issue_cycles_per_inst": round(4 * mix["normal_rate_4_cycles"] + 2 * mix["full_rate_2_cycles"] + 4 * mix["packed_or_64bit_4_cycles"] + 8 * mix["transcendental_8_cycles"], 3),

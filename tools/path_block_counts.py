@@ -1,10 +1,10 @@
 """Developer tool (GPU box): how often a wave of k_path ENTERS each block of its persistent loop (the blocks behind a wave-level branch), on the bench
 workload.  Needs the counting variant:
     ADYPT_BLOCKS_COUNT=1 tools/build_variant.sh blockcnt --transform adypt_amd/csrc/measure/k_path_blocks.py
-    ADYPT_LIB=adypt_amd/libadypt_blockcnt.so python tools/path_block_counts.py > profiles/r5_k_path_block_counts.json
+    ADYPT_LIB=adypt_amd/libadypt_blockcnt.so python tools/path_block_counts.py > profiles/r6_k_path_block_counts.json
     ADYPT_BLOCKS_COUNT=1 ADYPT_BLOCKS_SET=shade tools/build_variant.sh shadecnt --transform adypt_amd/csrc/measure/k_path_blocks.py
-    ADYPT_BLOCKS_SET=shade ADYPT_LIB=adypt_amd/libadypt_shadecnt.so python tools/path_block_counts.py > profiles/r5_k_path_shade_block_counts.json
-    (and the same with `rare` / rarecnt -> profiles/r5_k_path_rare_block_counts.json)
+    ADYPT_BLOCKS_SET=shade ADYPT_LIB=adypt_amd/libadypt_shadecnt.so python tools/path_block_counts.py > profiles/r6_k_path_shade_block_counts.json
+    (and the same with `rare` / rarecnt -> profiles/r6_k_path_rare_block_counts.json)
 With tools/trip_budget.py's static counts these are the EXECUTED vector instructions per trip, which tools/valu_issue_model.py checks against SQ_INSTS_VALU."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -22,7 +22,7 @@ p.SetInstrumentation(timing=True)
 p.Trace(True, 16 if fif else 5); p.DeviceSynchronize(); p.ResetStats()
 p.Trace(True, frames); p.DeviceSynchronize()
 s = p.GetStats(); wp = list(p.GetWaveProfile().values())
-trips = wp[7] >> 40; stamp = (wp[7] & ((1 << 40) - 1)) / max(1, trips)
+trips = wp[7] >> 36; stamp = (wp[7] & ((1 << 36) - 1)) / max(1, trips)
 clock = p.GetShaderClockGHz()
 sec = {n: round(wp[i] / max(1, trips), 1) for i, n in enumerate(NAMES)}
 total = sum(wp[:7]) / max(1, trips)

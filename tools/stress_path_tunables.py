@@ -19,7 +19,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for i in range(n):
-    env = {"ADYPT_RARE_MIN": rnd.choice([0, 1, 2, 5, 16, 33, 48, 64]), "ADYPT_SHADE_MIN": rnd.choice([1, 3, 9, 24, 47, 64]), "ADYPT_REFILL_MIN": rnd.choice([1, 4, 7, 16, 31, 64]),
+    env = {"ADYPT_REF_TRIANGLES_MAX_MB": rnd.choice(["", "", "0"]), "ADYPT_RARE_MIN": rnd.choice([0, 1, 2, 5, 16, 33, 48, 64]), "ADYPT_SHADE_MIN": rnd.choice([1, 3, 9, 24, 47, 64]), "ADYPT_REFILL_MIN": rnd.choice([1, 4, 7, 16, 31, 64]),
            "ADYPT_PATH_BLOCKS_PER_CU": rnd.choice([1, 1, 2, 4, 6]), "ADYPT_DEFER_MAX": rnd.choice([0, 1, 8, 24, 64])}
     if rnd.random() < 0.3: env["ADYPT_PATH_LDS_DEPTH"] = rnd.choice([1, 2, 3])
     if rnd.random() < 0.3: env["ADYPT_FRAMES_IN_FLIGHT"] = rnd.choice([2, 3, 5])

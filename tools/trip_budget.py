@@ -9,7 +9,7 @@ are scheduling barriers).  Dynamic weights (how often a block runs) come from to
 import collections, json, os, re, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "adypt_amd", "csrc")
-FN = "_ZN5adypt6k_pathILb0EEEvNS_12PathKernArgsE"
+FN = "_ZN5adypt6k_pathILb0ELb0EEEvNS_12PathKernArgsE"
 FULL = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_add_u32", "v_sub_u32",
         "v_subrev_u32", "v_ashrrev_i32", "v_mov_b32", "v_add_co_u32", "v_sub_co_u32", "v_addc_co_u32", "v_subb_co_u32", "v_add_i32", "v_sub_i32"}
 TRANS = ("v_rcp", "v_rsq", "v_sqrt", "v_exp", "v_log", "v_sin", "v_cos")
@@ -135,7 +135,7 @@ def main():
             pm.setdefault(m.group(1), i)
     plo, phi = loop_bounds(product, pm["exchange_end"])
     print(json.dumps({
-        "kernel": "k_path<false>", "what": __doc__.split("\n    python")[0], "flags": " ".join(flags),
+        "kernel": "k_path<false, false>", "what": __doc__.split("\n    python")[0], "flags": " ".join(flags),
         "blocks": dict(sorted(blocks.items())),
         "trip_valu_static_marked_build": trip_total,
         "trip_valu_static_product_build": count(product[pm["exchange_end"]:phi + 1])["valu"],

@@ -1,22 +1,22 @@
-"""Build profiles/r5_valu_issue_model.json (read by bench.py): the vector-ALU issue model of k_path<false>, weighted by EXECUTED instructions.
+"""Build profiles/r6_valu_issue_model.json (read by bench.py): the vector-ALU issue model of k_path<false>, weighted by EXECUTED instructions.
 
-  static counts   profiles/r5_trip_budget.json      tools/trip_budget.py: vector instructions per block of the persistent loop, by issue class (no GPU)
-  block entries   profiles/r5_k_path_block_counts.json, r5_k_path_shade_block_counts.json, r5_k_path_rare_block_counts.json
+  static counts   profiles/r6_trip_budget.json      tools/trip_budget.py: vector instructions per block of the persistent loop, by issue class (no GPU)
+  block entries   profiles/r6_k_path_block_counts.json, r6_k_path_shade_block_counts.json, r6_k_path_rare_block_counts.json
                                                      tools/path_block_counts.py: how often a wave enters each block (three counting variants, GPU)
   issue cycles    profiles/r3_valu_calibration.json  one-instruction loops: TRUE cycles a wave-instruction holds its SIMD's issue, per class
-  check           profiles/r5_pmc_bench.json         SQ_INSTS_VALU per ray of the product kernel (rocprofv3 --pmc, tools/collect_profiles.sh)
+  check           profiles/r6_pmc_bench.json         SQ_INSTS_VALU per ray of the product kernel (rocprofv3 --pmc, tools/collect_profiles.sh)
 
 executed instructions per wave-trip = sum over blocks (static x entries / trips); it must reproduce SQ_INSTS_VALU per wave-trip
 (= SQ_INSTS_VALU per ray / wave-trips per ray) within 3 % — tests/test_profiles_consistency.py asserts it.  Round 4's model weighted a static
 count of the whole loop and was off by 65 %.
-    python tools/valu_issue_model.py > profiles/r5_valu_issue_model.json"""
+    python tools/valu_issue_model.py > profiles/r6_valu_issue_model.json"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda n: os.path.join(ROOT, "profiles", n)
 cal = {r["kernel"]: r for r in json.load(open(P("r3_valu_calibration.json")))["rows"]}
-budget = json.load(open(P("r5_trip_budget.json")))
-counts = json.load(open(P("r5_k_path_block_counts.json")))
-pmc = json.load(open(P("r5_pmc_bench.json"))) if os.path.exists(P("r5_pmc_bench.json")) else None
+budget = json.load(open(P("r6_trip_budget.json")))
+counts = json.load(open(P("r6_k_path_block_counts.json")))
+pmc = json.load(open(P("r6_pmc_bench.json"))) if os.path.exists(P("r6_pmc_bench.json")) else None
 old = json.load(open(P("r4_k_path_instruction_mix.json")))
 
 CLASSES = [
@@ -32,7 +32,7 @@ CLASSES = [
 entries = counts["wave_entries"]
 trips = float(entries["trip"])
 w = {k: v / trips for k, v in entries.items()}
-for name in ("r5_k_path_shade_block_counts.json", "r5_k_path_rare_block_counts.json"):
+for name in ("r6_k_path_shade_block_counts.json", "r6_k_path_rare_block_counts.json"):
     if not os.path.exists(P(name)):
         continue
     e = json.load(open(P(name)))["wave_entries"]
@@ -77,7 +77,7 @@ for key, label, cycles, kernels in CLASSES:
     arch += share * cycles
     loops += share * m
 out = {
-    "kernel": "k_path<false>",
+    "kernel": "k_path<false, false>",
     "what": __doc__.split("\n    python")[0],
     "blocks": rows,
     "executed_valu_per_wave_trip_model": round(total, 1),
@@ -91,7 +91,7 @@ out = {
 if pmc:
     measured = pmc["valu_insts_per_ray"] / counts["wave_trips_per_ray"]
     out.update({"executed_valu_per_wave_trip_measured": round(measured, 1), "model_over_measured": round(total / measured, 4),
-                "measured_from": "profiles/r5_pmc_bench.json: SQ_INSTS_VALU per ray %.2f / wave-trips per ray %.5f (the counting variant's trips; the product's own scheduling "
+                "measured_from": "profiles/r6_pmc_bench.json: SQ_INSTS_VALU per ray %.2f / wave-trips per ray %.5f (the counting variant's trips; the product's own scheduling "
                                  "may differ by a fraction of a percent)" % (pmc["valu_insts_per_ray"], counts["wave_trips_per_ray"]),
                 "pmc_source_hash": pmc.get("source_hash")})
 print(json.dumps(out, indent=1))
