@@ -43,7 +43,10 @@ def test_register_budget_of_the_hot_kernels():
 @pytest.mark.gpu
 def test_k_path_rate_against_the_committed_line(scene_cache):
     from adypt_amd import api, scenes
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r6_bench_json_driver_command.json")).read().strip().splitlines()[-1])
+    path = os.path.join(ROOT, "profiles", "r6_bench_json_driver_command.json")
+    if not os.path.exists(path):
+        pytest.skip("no committed line of the driver's command for this round yet (tools/full_cycle.sh + tools/finalize_bench_profiles.py write it)")
+    line = json.loads(open(path).read().strip().splitlines()[-1])
     want = line["roofline"]["kernel_Mrays_s"]
     spec = scenes.make_scene("sponza", scene_cache, width=1920, height=1080, pt={"maxBounce": 8, "tmpLifetime": 16, "stackSize": 24, "subpixel": 8, "clamp": 4.0, "sun": [12.0, 11.0, 10.0]})
     inst = api.Instance()
