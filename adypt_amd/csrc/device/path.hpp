@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kTraceThreads, STATS ? 4 : ADYPT_PATH_WAVES) void k
 	// Shape of the loop: NO `continue`.  Every iteration runs top to bottom — start rays, exchange, trip — and a wave-uniform flag skips the
 	// trip when the exchange handed out rays (they are started first) or the wave holds none.  With `continue` edges around the trip the
 	// loop-carried ray state lived in two register sets, one for the blocks in front of the trip and one for the trip, with 10 copies at the
-	// loop's latch and more at the trip's head: ~17 of a trip's ~340 vector instructions (profiles/r5_trip_budget.json).
+	// loop's latch and more at the trip's head: ~17 of a trip's ~340 vector instructions (profiles/history/r5_trip_budget.json).
 	bool any_setup = __ballot(setup) != 0ull; // wave-uniform: some lane is about to start a ray (kept instead of a vote per iteration)
 	for(;;)
 	{

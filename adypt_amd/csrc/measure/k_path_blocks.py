@@ -2,7 +2,7 @@
 branch — is bracketed by `; ADYPT_MARK <name>_begin / _end` comments in the assembly and counts, in an SGPR, how often a wave ENTERS it (an s_add in the
 block itself: it runs exactly when the block's vector instructions are issued, whatever the lanes' masks).  tools/trip_budget.py reads the static
 instruction counts between the marks (no GPU needed); tools/path_block_counts.py reads the entry counts on the GPU box; together they are the EXECUTED
-vector instructions per trip (profiles/r5_trip_budget.json, r5_k_path_block_counts.json), which tools/valu_issue_model.py checks against SQ_INSTS_VALU.
+vector instructions per trip (profiles/r6_trip_budget.json, r6_k_path_block_counts.json), which tools/valu_issue_model.py checks against SQ_INSTS_VALU.
     tools/build_variant.sh blocks --transform adypt_amd/csrc/measure/k_path_blocks.py
 Three counting passes (twelve counters each: ADYPT_BLOCKS_SET = trip | shade | rare); every mark is inserted in every pass.  Blocks: setup | exchange | shade | trip;
 inside the trip A_pop (A_pop_spill) A_choose A_push (A_push_spill) B_tri_load B_node_load C_woop D_slab E_flush; inside a shading round S_parked S_miss S_surface

@@ -102,6 +102,14 @@ def valu_roofline(pmc, model, kernel_rays_s, live_clock_ghz=0.0):
            "valu_insts_per_ray": round(pmc["valu_insts_per_ray"], 2), "valu_Ginst_s": round(inst_rate / 1e9, 1),
            "issue_cycles_per_inst_architectural": arch, "issue_cycles_available_per_inst": round(peak * 1e9 / inst_rate, 3),
            "pmc_stale": False, "pmc_source_hash": pmc["source_hash"]}
+    if "lds_insts_per_ray" in pmc:
+        # Round 6: an LDS or vector-memory instruction holds the SIMD's issue like a "normal" vector-ALU one (operands and results pass through the same register
+        # file: 64 vector-ALU + 8 ds_bpermute_b32 cost what 72 vector-ALU do, tools/microbench/lds_xbar.hip) — so the roof the kernel runs into is the one over
+        # ALL its vector instructions, and a trip that trades vector-ALU for LDS instructions (the triangle list of round 6) moves `frac` but not this figure
+        other = (pmc["lds_insts_per_ray"] + pmc.get("vmem_rd_insts_per_ray", 0.0)) * kernel_rays_s * 4.0 / 1e9
+        out["all_vector_instructions"] = {"valu_per_ray": round(pmc["valu_insts_per_ray"], 2), "lds_per_ray": round(pmc["lds_insts_per_ray"], 2), "vmem_rd_per_ray": round(pmc.get("vmem_rd_insts_per_ray", 0.0), 2),
+                                          "achieved": round(achieved + other, 1), "frac": round((achieved + other) / peak, 4),
+                                          "what": "issue cycles of the vector-ALU instructions (architectural rates) + 4 cycles per LDS and per vector-memory instruction, against 1024 SIMDs x the clock"}
     if model:
         loops = model["avg_issue_cycles_per_inst_single_class_loops"]
         out["issue_cycles_per_inst_single_class_loops"] = loops

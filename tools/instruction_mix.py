@@ -1,5 +1,5 @@
 """(Round 4's tool; for k_path it is superseded by tools/trip_budget.py + tools/path_block_counts.py + tools/valu_issue_model.py, which weight the mix by
-EXECUTED instructions.  Kept for k_trace and because profiles/r5_valu_issue_model.json takes the vector-memory cost per load from its round-4 output.)
+EXECUTED instructions.  Kept for k_trace and because profiles/r6_valu_issue_model.json takes the vector-memory cost per load from its round-4 output.)
 Static instruction mix of the dominant kernel's persistent loop, by vector-ALU issue class (profiles/r3_valu_calibration.json).
 Compiles device/tracer.hip with the Makefile's flags, takes k_path<false> (default) or k_trace<false,false> (argv[1] = "k_trace"), and counts
 the VALU instructions between the persistent loop's header and its last back edge (blocks before / after it run once per wave).  Blocks that

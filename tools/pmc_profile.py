@@ -33,6 +33,7 @@ fetch, write = per_kernel("FETCH_SIZE"), per_kernel("WRITE_SIZE")
 hit, req = per_kernel("TCC_HIT_sum"), per_kernel("TCC_REQ_sum")
 insts, tcyc = per_kernel("SQ_INSTS_VALU"), per_kernel("SQ_THREAD_CYCLES_VALU")
 vmem = per_kernel("SQ_INSTS_VMEM_RD")
+lds, salu = per_kernel("SQ_INSTS_LDS"), per_kernel("SQ_INSTS_SALU")
 busy, wcyc, gui = per_kernel("SQ_BUSY_CYCLES"), per_kernel("SQ_WAVE_CYCLES"), per_kernel("GRBM_GUI_ACTIVE")
 active_valu = per_kernel("SQ_ACTIVE_INST_VALU")
 N_XCD, N_SIMD = 8, 1024
@@ -53,6 +54,7 @@ out = {
     "valu_insts_per_ray": sum(insts) / max(1, rays),
     "lane_util": sum(tcyc) / max(1.0, 64.0 * sum(insts)),
     "vmem_rd_insts_per_ray": sum(vmem) / max(1, rays),
+    "lds_insts_per_ray": sum(lds) / max(1, rays), "salu_insts_per_ray": sum(salu) / max(1, rays),  # (an LDS instruction costs the SIMD an issue slot like a vector-ALU one: profiles/r6_ablations.txt 3)
     "GRBM_GUI_ACTIVE_per_launch": sum(gui) / max(1, len(gui)),
     "traffic_bytes_per_ray_uncorrected": (sum(fetch) * 1024 + sum(write) * 1024) / max(1, rays),
     "SQ_ACTIVE_INST_VALU_per_launch": sum(active_valu) / max(1, len(active_valu)),

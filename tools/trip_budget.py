@@ -5,7 +5,7 @@ compiled to gfx950 assembly with the Makefile's flags, and the VALU instructions
   blocks: the parts behind a wave-level branch (skipped when no lane needs them), nested as in the source; `trip/X` = what every trip issues in section X.
 The product library has no marks inside the trip; its own totals are printed beside the marked build's (they differ by a few instructions: the marks
 are scheduling barriers).  Dynamic weights (how often a block runs) come from tools/path_block_counts.py on the GPU box.
-    python tools/trip_budget.py > profiles/r5_trip_budget.json"""
+    python tools/trip_budget.py > profiles/r6_trip_budget.json"""
 import collections, json, os, re, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "adypt_amd", "csrc")
