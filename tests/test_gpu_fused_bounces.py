@@ -39,11 +39,13 @@ def _instance(cache, name, w, h, pt, seed=31, **kw):
     return inst
 
 
-def _render(cache, name, w, h, pt, spp, fused, env=None, calls=None, **kw):
+def _render(cache, name, w, h, pt, spp, fused, env=None, calls=None, sun=None, **kw):
     with environment(**(env or {})):
         inst = _instance(cache, name, w, h, pt, **kw)
     p = inst.m_path_tracer
     p.SetFusedBounces(fused)
+    if sun is not None:
+        p.SetSunVisibility(True, sun)   # every escaped path sends its occlusion query: inside k_path<., SUN> / through the launch-per-bounce pipeline's query queue
     p.SetInstrumentation(counters=True)
     p.ResetStats()
     for n in (calls or [spp]):
@@ -114,6 +116,23 @@ def test_scheduling_tunables_do_not_change_a_bit(env, scene_cache):
     one = _render(scene_cache, "tiny0", 120, 68, pt, 10, fused=True, env=env)
     assert one["stats"]["path_rays"] > 0  # (with 3 frames in flight the tenth frame is a batch of one, traced bounce by bounce)
     _same(ref, one, str(env))
+
+
+@pytest.mark.parametrize("env", [
+    {},
+    {"ADYPT_SHADE_MIN": 1, "ADYPT_REFILL_MIN": 1},
+    {"ADYPT_PATH_BLOCKS_PER_CU": 1, "ADYPT_RARE_MIN": 1, "ADYPT_PATH_LDS_DEPTH": 1},
+    {"ADYPT_FRAMES_IN_FLIGHT": 3, "ADYPT_REF_TRIANGLES_MAX_MB": 0},
+])
+def test_sun_visibility_queries_inside_the_launch_under_scheduling_tunables(env, scene_cache):
+    """The escaped paths' occlusion queries (rays that end at their first accepted triangle, among closest-hit rays, in one launch) against the launch-per-bounce
+    pipeline's query queue + any-hit kernel: images, primary-hit cache and the exact ray / node / triangle / hit census, whatever the scheduling."""
+    pt = {"tmpLifetime": 3, "maxBounce": 6, "subpixel": 2, "stackSize": 24}
+    for name, w, h in (("tiny0", 120, 68), ("sibenik", 96, 54)):
+        ref = _render(scene_cache, name, w, h, pt, 8, fused=False, env={k: v for k, v in env.items() if k == "ADYPT_FRAMES_IN_FLIGHT"}, sun=[-0.3, 0.8, 0.5])
+        one = _render(scene_cache, name, w, h, pt, 8, fused=True, env=env, sun=[-0.3, 0.8, 0.5])
+        assert one["stats"]["path_rays"] > 0 and one["stats"]["rays"] > _render(scene_cache, name, w, h, pt, 8, fused=True, env=env)["stats"]["rays"]  # (the queries are rays)
+        _same(ref, one, name + str(env))
 
 
 @pytest.mark.parametrize("nranks", [2, 3, 7])

@@ -10,8 +10,8 @@ import numpy as np
 from tests.test_gpu_fused_bounces import _render, _same
 case = json.loads(sys.argv[1])
 cache = os.environ.get("ADYPT_CACHE", "/tmp/adypt_cache")
-ref = _render(cache, case["scene"], case["w"], case["h"], case["pt"], case["spp"], fused=False, env={k: v for k, v in case["env"].items() if k == "ADYPT_FRAMES_IN_FLIGHT"})
-one = _render(cache, case["scene"], case["w"], case["h"], case["pt"], case["spp"], fused=True, env=case["env"])
+ref = _render(cache, case["scene"], case["w"], case["h"], case["pt"], case["spp"], fused=False, env={k: v for k, v in case["env"].items() if k == "ADYPT_FRAMES_IN_FLIGHT"}, sun=case.get("sun"))
+one = _render(cache, case["scene"], case["w"], case["h"], case["pt"], case["spp"], fused=True, env=case["env"], sun=case.get("sun"))
 _same(ref, one, json.dumps(case))
 print("ok", one["stats"]["path_rays"])
 ''' % ROOT
@@ -26,7 +26,7 @@ for i in range(n):
     big = os.environ.get("STRESS_BIG", "0") != "0"   # the bench scene at up to 960 x 540: workgroups that hold full tables, rounds that defer
     scene = rnd.choice(["sponza", "sponza", "sibenik"] if big else ["tiny0", "tiny0", "sibenik"])
     w, h = rnd.choice([(480, 270), (640, 360), (960, 540)] if big else [(64, 40), (120, 68), (200, 120), (320, 200)])
-    case = {"scene": scene, "w": w, "h": h, "spp": rnd.choice([5, 8, 12]), "env": env,
+    case = {"scene": scene, "w": w, "h": h, "spp": rnd.choice([5, 8, 12]), "env": env, "sun": rnd.choice([None, None, [0.6, 1.0, 0.2], [-0.3, 0.8, 0.5]]),
             "pt": {"tmpLifetime": rnd.choice([1, 3, 4, 16]), "maxBounce": rnd.choice([2, 5, 8, 13]), "subpixel": rnd.choice([1, 2, 3]), "stackSize": 24}}
     try:
         r = subprocess.run([sys.executable, "-c", CHILD, json.dumps(case)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, cwd=ROOT)
