@@ -158,11 +158,13 @@ def test_tile_shards_with_one_launch_reassemble_bit_exact(nranks, scene_cache):
 
 def test_stack_overflow_is_reported_by_the_fused_launch_too(scene_cache):
     spec = scenes.make_scene("sibenik", scene_cache, width=96, height=54, pt={"tmpLifetime": 4, "maxBounce": 4, "stackSize": 1})
-    for fused in (False, True):
+    for fused, sun in ((False, False), (True, False), (True, True)):   # (with the sun-visibility queries in the launch a failed push is committed when its node is visited)
         inst = api.Instance()
         assert inst.InitializeFromFile(spec.config_path, shift_seed=5)
         p = inst.m_path_tracer
         p.SetFusedBounces(fused)
+        if sun:
+            p.SetSunVisibility(True)
         with pytest.raises(N.AdyptError) as e:
             p.Trace(True, 6)
         assert e.value.code == N.E_STACK_OVERFLOW
