@@ -219,7 +219,7 @@ int adypt_set_instrumentation(adypt_ctx *ctx, int flags);
 int adypt_get_stats(adypt_ctx *ctx, adypt_stats *out);
 int adypt_reset_stats(adypt_ctx *ctx);
 /* SIMD-occupancy profile of the instrumented traversal launches since the last reset (measurement only; wave-level
- * sums): out[0] loop trips, [1] lanes holding a ray summed over trips, [2] triangle-pair iterations, [3] lanes active
+ * sums): out[0] loop trips, [1] lanes holding a ray summed over trips, [2] trips in which the wave ran its Woop test, [3] lanes testing a triangle
  * summed over those, [4] slab-test phases executed, [5] lanes active summed over those, [6] refill events,
  * [7] trips with no lane holding a ray. */
 int adypt_get_wave_profile(adypt_ctx *ctx, uint64_t out[8]);
